@@ -1,0 +1,285 @@
+"""
+TEST INFRASTRUCTURE ONLY.  CPU oracle for the acoustic FWI hot path of LongyanU/devito-fwi.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module,
+and only as the checker / reported CPU baseline.  The shipped package never does.
+
+Two layers:
+  * ctypes bindings to oracle/liboracle.so (acoustic_oracle.c): forward / adjoint / gradient
+    time loops, sponge profile, FD weights, CFL coefficient.
+  * numpy restatements of the host-side set-up and FWI glue the reference runs around the
+    propagators, each citing the reference file:line it follows.
+
+Parity status: PINNED (tests/test_oracle_kat.py reproduces seismic/inversion/fwi.py:95-97,121
+and seismic/acoustic/acoustic_example.py:75-79).
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+def build(force=False):
+    """Compile oracle/liboracle.so with the committed Makefile (gcc + OpenMP)."""
+    so = os.path.join(_HERE, "liboracle.so")
+    srcs = [os.path.join(_HERE, f) for f in ("acoustic_oracle.c", "acoustic_oracle_impl.h", "Makefile")]
+    stale = (not os.path.exists(so)) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs)
+    if force or stale:
+        subprocess.check_call(["make", "-C", _HERE, "-B", "liboracle.so"], stdout=subprocess.DEVNULL)
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        so = os.path.join(_HERE, "liboracle.so")
+        if not os.path.exists(so):
+            build()
+        _LIB = ctypes.CDLL(so)
+        _LIB.oracle_cfl_coeff.restype = ctypes.c_double
+        _LIB.oracle_cfl_coeff.argtypes = [ctypes.c_int, ctypes.c_int]
+    return _LIB
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(ctypes.c_void_p)
+
+
+def _ia(v):
+    return (ctypes.c_int * len(v))(*[int(x) for x in v])
+
+
+def _da(v):
+    return (ctypes.c_double * len(v))(*[float(x) for x in v])
+
+
+def _sfx(dtype):
+    dtype = np.dtype(dtype)
+    if dtype == np.float32:
+        return "f32"
+    if dtype == np.float64:
+        return "f64"
+    raise TypeError(dtype)
+
+
+# ----------------------------------------------------------------------------------------------
+# numerical constants
+# ----------------------------------------------------------------------------------------------
+def fd2_weights(radius):
+    """w[0..R] of the centred 2nd-derivative stencil (sympy fd_w(2, range(-R,R+1), 0)[-1][-1])."""
+    w = np.zeros(radius + 1)
+    lib().oracle_fd2_weights(ctypes.c_int(radius), _p(w))
+    return w
+
+
+def cfl_coeff(space_order, ndim):
+    """seismic/model.py:338-353."""
+    return lib().oracle_cfl_coeff(space_order, ndim)
+
+
+def critical_dt(vp_max, spacing, space_order, dtype=np.float32, dt=None):
+    """seismic/model.py:355-370, including the local edit honouring a user dt."""
+    ndim = len(spacing)
+    cdt = cfl_coeff(space_order, ndim) * np.min(spacing) / vp_max
+    cdt = np.dtype(dtype).type("%.3e" % cdt)
+    if dt:
+        if dt > cdt:
+            raise ValueError("Critical dt: %f, set dt: %f" % (cdt, dt))
+        return dt
+    return cdt
+
+
+def sponge(shape_pad, nbl, spacing, dtype=np.float32):
+    """seismic/model.py:13-51 (abc_type='damp', fs=False)."""
+    dtype = np.dtype(dtype)
+    out = np.zeros(tuple(shape_pad), dtype=dtype)
+    fn = getattr(lib(), "oracle_sponge_" + _sfx(dtype))
+    rc = fn(len(shape_pad), _ia(shape_pad), int(nbl), _da(spacing), _p(out))
+    assert rc == 0
+    return out
+
+
+def pad_vp(vp, nbl):
+    """seismic/model.py:174,387: initialize_function replicates edge values into the layer."""
+    return np.pad(vp, nbl, mode="edge") if nbl > 0 else np.array(vp)
+
+
+def time_axis(t0, tn, dt):
+    """seismic/source.py:42-75: num = ceil((stop-start+step)/step); values = linspace."""
+    num = int(np.ceil((tn - t0 + dt) / dt))
+    stop = dt * (num - 1) + t0
+    return num, np.linspace(t0, stop, num)
+
+
+def ricker(f0, time_values, t0=None, a=None):
+    """seismic/source.py:272-277."""
+    t0 = t0 or 1.0 / f0
+    a = a or 1
+    r = np.pi * f0 * (time_values - t0)
+    return a * (1 - 2.0 * r ** 2) * np.exp(-r ** 2)
+
+
+# ----------------------------------------------------------------------------------------------
+# propagators
+# ----------------------------------------------------------------------------------------------
+class Problem(object):
+    """
+    One padded acoustic model + discretisation, as `SeismicModel` + `AcousticWaveSolver`
+    define it (seismic/model.py:91-124,227-283; seismic/acoustic/wavesolver.py:28-46).
+
+    vp      physical-domain velocity (km/s), any of 1-3 dims
+    """
+
+    def __init__(self, vp, spacing, nbl, space_order, origin=None, dtype=np.float32, dt=None,
+                 model_space_order=None):
+        self.dtype = np.dtype(dtype)
+        vp = np.asarray(vp, dtype=self.dtype)
+        self.ndim = vp.ndim
+        self.shape = vp.shape
+        self.nbl = int(nbl)
+        self.spacing = tuple(float(s) for s in spacing)
+        self.origin = tuple(float(o) for o in (origin or (0.0,) * self.ndim))
+        self.space_order = int(space_order)
+        self.model_space_order = int(model_space_order or space_order)
+        self.user_dt = dt
+        # model.py:100: origin_pml = dtype(o - s*nbl)
+        self.origin_pad = tuple(float(self.dtype.type(o - s * self.nbl)) for o, s in zip(self.origin, self.spacing))
+        self.shape_pad = tuple(s + 2 * self.nbl for s in self.shape)
+        self.damp = sponge(self.shape_pad, self.nbl, self.spacing, self.dtype)
+        self.set_vp(vp)
+
+    def set_vp(self, vp):
+        vp = np.asarray(vp, dtype=self.dtype)
+        if vp.shape == self.shape:
+            self.vp = np.ascontiguousarray(pad_vp(vp, self.nbl))
+        elif vp.shape == self.shape_pad:
+            self.vp = np.ascontiguousarray(vp)
+        else:
+            raise ValueError("bad vp shape %s" % (vp.shape,))
+
+    @property
+    def critical_dt(self):
+        return critical_dt(float(self.vp.max()), self.spacing, self.model_space_order, self.dtype, self.user_dt)
+
+    def _coords(self, c):
+        return np.ascontiguousarray(np.asarray(c, dtype=self.dtype).reshape(-1, self.ndim))
+
+    def forward(self, src_coords, wavelet, rec_coords, dt=None, save=False, vp=None, return_last=False):
+        """operators.py:98-140.  wavelet (nt, nsrc).  Returns rec (nt,nrec) [, u (nt,*shape_pad)]."""
+        dt = float(self.critical_dt if dt is None else dt)
+        vp = self.vp if vp is None else np.ascontiguousarray(vp, dtype=self.dtype)
+        sc, rc_ = self._coords(src_coords), self._coords(rec_coords)
+        w = np.ascontiguousarray(np.asarray(wavelet, dtype=self.dtype).reshape(-1, sc.shape[0]))
+        nt = w.shape[0]
+        rec = np.zeros((nt, rc_.shape[0]), dtype=self.dtype)
+        u = np.zeros((nt,) + self.shape_pad, dtype=self.dtype) if save else None
+        ul = np.zeros((3,) + self.shape_pad, dtype=self.dtype) if return_last else None
+        fn = getattr(lib(), "oracle_forward_" + _sfx(self.dtype))
+        rc = fn(self.ndim, _ia(self.shape_pad), _da(self.spacing), _da(self.origin_pad), self.space_order,
+                nt, ctypes.c_double(dt), _p(vp), _p(self.damp), sc.shape[0], _p(sc), _p(w),
+                rc_.shape[0], _p(rc_), _p(rec), _p(u), _p(ul))
+        assert rc == 0, rc
+        out = (rec, u)
+        return out + (ul,) if return_last else out
+
+    def adjoint(self, src_coords, rec_coords, rec, dt=None, vp=None):
+        """operators.py:143-180.  rec (nt,nrec) -> srca (nt,nsrc)."""
+        dt = float(self.critical_dt if dt is None else dt)
+        vp = self.vp if vp is None else np.ascontiguousarray(vp, dtype=self.dtype)
+        sc, rc_ = self._coords(src_coords), self._coords(rec_coords)
+        rec = np.ascontiguousarray(rec, dtype=self.dtype)
+        nt = rec.shape[0]
+        srca = np.zeros((nt, sc.shape[0]), dtype=self.dtype)
+        fn = getattr(lib(), "oracle_adjoint_" + _sfx(self.dtype))
+        rc = fn(self.ndim, _ia(self.shape_pad), _da(self.spacing), _da(self.origin_pad), self.space_order,
+                nt, ctypes.c_double(dt), _p(vp), _p(self.damp), sc.shape[0], _p(sc), _p(srca),
+                rc_.shape[0], _p(rc_), _p(rec), None)
+        assert rc == 0, rc
+        return srca
+
+    def gradient(self, rec_coords, residual, u, dt=None, vp=None, grad=None):
+        """operators.py:183-225.  Accumulates into grad (padded grid) and returns it."""
+        dt = float(self.critical_dt if dt is None else dt)
+        vp = self.vp if vp is None else np.ascontiguousarray(vp, dtype=self.dtype)
+        rc_ = self._coords(rec_coords)
+        residual = np.ascontiguousarray(residual, dtype=self.dtype)
+        u = np.ascontiguousarray(u, dtype=self.dtype)
+        nt = residual.shape[0]
+        assert u.shape == (nt,) + self.shape_pad
+        if grad is None:
+            grad = np.zeros(self.shape_pad, dtype=self.dtype)
+        assert grad.flags.c_contiguous and grad.dtype == self.dtype
+        fn = getattr(lib(), "oracle_gradient_" + _sfx(self.dtype))
+        rc = fn(self.ndim, _ia(self.shape_pad), _da(self.spacing), _da(self.origin_pad), self.space_order,
+                nt, ctypes.c_double(dt), _p(vp), _p(self.damp), rc_.shape[0], _p(rc_), _p(residual),
+                _p(u), _p(grad))
+        assert rc == 0, rc
+        return grad
+
+
+# ----------------------------------------------------------------------------------------------
+# FWI glue (fwi.py of the reference)
+# ----------------------------------------------------------------------------------------------
+def least_square(syn, obs):
+    """misfit/misfit.py:5-9."""
+    res = syn - obs
+    return 0.5 * np.linalg.norm(res.flatten()) ** 2, res
+
+
+def fix_source_illumination(shape, spacing, src_pos, rec_pos, g):
+    """fwi.py:104-129, including its meshgrid(z, x) transposition quirk (fwi.py:115)."""
+    dx, dz = spacing
+    sx, sz = src_pos[0], src_pos[1]
+    nx, nz = shape
+    x = np.arange(0, nx) * dx
+    z = np.arange(0, nz) * dz
+    xx, zz = np.meshgrid(z, x)
+    sigma = dx + dz
+    mask = np.exp(-.5 * ((xx - sx) ** 2 + (zz - sz) ** 2) / (sigma ** 2))
+    g = g * (1. - mask)
+    for i in range(rec_pos.shape[0]):
+        rx, rz = rec_pos[i, 0], rec_pos[i, 1]
+        mask = np.exp(-.5 * ((xx - rx) ** 2 + (zz - rz) ** 2) / (sigma ** 2))
+        g = g * (1. - mask)
+    return g
+
+
+def fwi_obj_single(prob, src_pos, rec_pos, wavelet, obs, dt=None, calc_grad=True):
+    """fwi.py:131-173 with the L2 misfit and no resampling (dt of data == dt of solver)."""
+    nbl = prob.nbl
+    pred, u = prob.forward(src_pos, wavelet, rec_pos, dt=dt, save=calc_grad)
+    fval, res = least_square(pred, obs)
+    if not calc_grad:
+        return fval, None, res, None
+    grad = prob.gradient(rec_pos, res, u, dt=dt)
+    crop = tuple(slice(nbl, -nbl) for _ in range(prob.ndim))
+    g = fix_source_illumination(prob.shape, prob.spacing, np.ravel(src_pos), np.asarray(rec_pos), np.array(grad)[crop])
+    illum = (u * u).sum(axis=0)[crop]
+    illum = fix_source_illumination(prob.shape, prob.spacing, np.ravel(src_pos), np.asarray(rec_pos), illum)
+    return fval, g, res, illum
+
+
+def fwi_obj_multi(prob, src_positions, rec_pos, wavelet, obs_list, dt=None, mask=None, precond=True,
+                  calc_grad=True):
+    """fwi.py:175-205."""
+    fval = 0.0
+    grad = np.zeros(prob.shape)
+    illum = np.zeros(prob.shape)
+    residuals = []
+    for i in range(len(src_positions)):
+        f_, g_, r_, il_ = fwi_obj_single(prob, src_positions[i], rec_pos, wavelet, obs_list[i], dt, calc_grad)
+        fval += f_
+        residuals.append(r_)
+        if calc_grad:
+            grad += g_
+            illum += il_
+    if calc_grad:
+        if precond:
+            grad /= np.sqrt(illum + 1e-30)
+        if mask is not None:
+            grad *= mask
+    return fval, grad.reshape(-1).astype(np.float64), residuals

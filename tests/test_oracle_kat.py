@@ -1,0 +1,104 @@
+"""
+Pins the CPU oracle against the reference's own known-answer tests:
+  * seismic/inversion/fwi.py:95-97,121     objective 39113, min/max grad -821/2442, 5th GD objective 3828 (atol 10)
+  * seismic/acoustic/acoustic_example.py:75-79   ||rec|| = 459.1678 (f64, no free surface, rtol 1e-3)
+plus unit pins of the constants (FD weights vs sympy, CFL dt, sponge centre value of
+seismic/test_seismic_utils.py:17-36).
+"""
+import numpy as np
+import pytest
+
+from oracle import oracle as orc
+from kat_setups import circle_kat, layers3d_kat
+
+
+def test_fd_weights_match_sympy():
+    from sympy import finite_diff_weights
+    for R in range(1, 9):
+        ref = np.array([float(x) for x in finite_diff_weights(2, range(-R, R + 1), 0)[-1][-1]])[R:]
+        np.testing.assert_allclose(orc.fd2_weights(R), ref, rtol=1e-13, atol=0)
+
+
+def test_cfl_dt_values():
+    # seismic/model.py:351-365; the 2.041 value is what makes nt = 491 in the circle KAT
+    assert orc.critical_dt(3.0, (10., 10.), 2) == np.float32(2.041)
+    from sympy import finite_diff_weights
+    c = finite_diff_weights(2, range(-8, 9), 0)[-1][-1]
+    ref = np.sqrt(4 / float(2 * sum(abs(x) for x in c)))
+    assert np.isclose(orc.cfl_coeff(8, 2), ref, rtol=1e-12)
+
+
+@pytest.mark.parametrize("nbl", [20, 0])
+def test_sponge_centre_and_shape(nbl):
+    # seismic/test_seismic_utils.py:17-36, "damp" flavour: centre value 0, padded shape
+    d = orc.sponge((21 + 2 * nbl, 21 + 2 * nbl), nbl, (10., 10.))
+    assert d.shape == (21 + 2 * nbl, 21 + 2 * nbl)
+    assert d[d.shape[0] // 2, d.shape[1] // 2] == 0
+    if nbl:
+        assert d[0, 0] > d[nbl - 1, nbl - 1] > 0
+        # corner = sum of the two 1-D profiles, edge midpoint = one of them
+        assert np.isclose(d[0, 0], 2 * d[0, d.shape[1] // 2], rtol=1e-6)
+
+
+def test_time_axis_and_ricker():
+    # seismic/test_seismic_utils.py:44-56: tn=250, dt=1 -> 251 samples
+    nt, tv = orc.time_axis(0.0, 250.0, 1.0)
+    assert nt == 251 and tv[-1] == 250.0
+    w = orc.ricker(0.010, tv)
+    assert np.isclose(w[100], 1.0)        # peak at t = 1/f0
+
+
+def _circle_fwi_gradient(c, prob, vp_in, wavelet, dt):
+    grad = np.zeros(prob.shape_pad, dtype=np.float32)
+    objective = 0.0
+    for i in range(c["src_positions"].shape[0]):
+        d_obs, _ = prob.forward(c["src_positions"][i], wavelet, c["rec_positions"], dt=dt)
+        d_syn, u0 = prob.forward(c["src_positions"][i], wavelet, c["rec_positions"], dt=dt, save=True, vp=vp_in)
+        residual = d_syn - d_obs
+        objective += .5 * np.linalg.norm(residual.ravel().astype(np.float64)) ** 2
+        prob.gradient(c["rec_positions"], residual, u0, dt=dt, vp=vp_in, grad=grad)
+    return objective, grad
+
+
+def test_kat_circle_fwi():
+    """seismic/inversion/fwi.py:59-121."""
+    c = circle_kat()
+    prob = orc.Problem(c["vp_true"], c["spacing"], c["nbl"], c["space_order"],
+                       model_space_order=c["model_space_order"])
+    dt = prob.critical_dt
+    assert dt == np.float32(2.041)
+    nt, tv = orc.time_axis(c["t0"], c["tn"], float(dt))
+    assert nt == 491
+    wavelet = orc.ricker(c["f0"], tv).astype(np.float32).reshape(nt, 1)
+    vp0 = orc.pad_vp(c["vp_init"], c["nbl"]).astype(np.float32)
+
+    ff, g = _circle_fwi_gradient(c, prob, vp0, wavelet, dt)
+    k = c["kat"]
+    print("circle KAT:", ff, g.min(), g.max())
+    assert np.isclose(ff, k["objective"], atol=k["atol"], rtol=0)
+    assert np.isclose(g.min(), k["gmin"], atol=k["atol"], rtol=0)
+    assert np.isclose(g.max(), k["gmax"], atol=k["atol"], rtol=0)
+
+    history = []
+    for it in range(5):
+        phi, direction = _circle_fwi_gradient(c, prob, vp0, wavelet, dt)
+        history.append(phi)
+        alpha = np.float32(.05 / direction.max())
+        # seismic/inversion/inversion_utils.py:28-39, on the padded grid
+        vp0 = np.clip(vp0 + alpha * direction, c["vmin"], c["vmax"]).astype(np.float32)
+    print("circle KAT history:", history)
+    assert np.isclose(history[-1], k["objective_it5"], atol=k["atol"], rtol=0)
+
+
+@pytest.mark.slow
+def test_kat_layers3d_forward_f64():
+    """seismic/acoustic/acoustic_example.py:75-79, (fs=False, 459.1678, float64)."""
+    c = layers3d_kat()
+    prob = orc.Problem(c["vp"], c["spacing"], c["nbl"], c["space_order"], dtype=np.float64)
+    dt = prob.critical_dt
+    nt, tv = orc.time_axis(c["t0"], c["tn"], float(dt))
+    wavelet = orc.ricker(c["f0"], tv).reshape(nt, 1)
+    rec, _ = prob.forward(c["src_positions"], wavelet, c["rec_positions"], dt=dt)
+    nrm = np.linalg.norm(rec.ravel())
+    print("layers3d KAT: dt", dt, "nt", nt, "norm", nrm)
+    assert np.isclose(nrm, c["kat"]["norm_rec"], rtol=c["kat"]["rtol"], atol=0)
