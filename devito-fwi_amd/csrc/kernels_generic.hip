@@ -1,0 +1,343 @@
+// Untiled reference kernels of libmifwi: one thread per grid point, neighbours read through the
+// vector L1/L2.  They cover every case the ABI accepts (1-3 dims, space orders 2..16, f32 and
+// f64) and are the fallback of the tiled fast paths.  Also here: the sparse source/receiver
+// kernel, model preparation, halo pack/unpack and the L2-misfit reduction.
+//
+// Discrete equations (seismic/acoustic/operators.py:59-95 of the reference, with the one-sided
+// damping term that its known-answer tests pin):
+//     out = ( dt^2 L(cur) + 2 m cur - m old + eta dt cur ) / ( m + eta dt )
+//     L(u) = c0 u + sum_d sum_{k=1..R} c[d][k] (u[-k e_d] + u[+k e_d])
+// The same update serves forward (old = u[t-1], out = u[t+1]) and backward propagation
+// (old = v[t+1], out = v[t-1]).  The gradient variant additionally accumulates
+//     grad += -(u[t-1] - 2 u[t] + u[t+1]) / dt^2 * v[t]      (operators.py:216-217)
+// and, optionally, illum += u[t]^2 (fwi.py:170).
+#include "mifwi_internal.hpp"
+
+namespace mifwi {
+
+template <typename T, int R, int ND, bool GRAD>
+__global__ __launch_bounds__(256) void step_generic_kernel(StepConsts<T> k, StepPtrs<T> sp, GradPtrs<T> gp)
+{
+    const int i2 = blockIdx.x * 64 + threadIdx.x;
+    const int i1 = blockIdx.y * 4 + threadIdx.y;
+    const int shot = blockIdx.z / k.n0;
+    const int i0 = blockIdx.z - shot * k.n0;
+    if (i2 >= k.n2 || i1 >= k.n1) return;
+    const long p = k.off0 + (long)i0 * k.s0 + (long)i1 * k.s1 + i2;
+    const T *cur = sp.cur + (long)shot * sp.shot_stride + p;
+    const T uc = cur[0];
+    T lap = k.c0 * uc;
+#pragma unroll
+    for (int j = 1; j <= R; ++j) lap += k.c[2][j] * (cur[-j] + cur[j]);
+    if (ND >= 2) {
+#pragma unroll
+        for (int j = 1; j <= R; ++j) lap += k.c[1][j] * (cur[-j * k.s1] + cur[j * k.s1]);
+    }
+    if (ND >= 3) {
+#pragma unroll
+        for (int j = 1; j <= R; ++j) lap += k.c[0][j] * (cur[-j * k.s0] + cur[j * k.s0]);
+    }
+    const T mz = sp.m[p];
+    const T ed = sp.eta[p] * k.dt;
+    const T uo = sp.old[(long)shot * sp.shot_stride + p];
+    sp.out[(long)shot * sp.shot_stride + p] = (k.dt2 * lap + T(2) * mz * uc - mz * uo + ed * uc) / (mz + ed);
+    if (GRAD) {
+        const long q = (long)shot * gp.u_shot_stride + p;
+        const T um = gp.um[q], u0 = gp.uc[q], up = gp.up[q];
+        const long g = (long)shot * gp.g_shot_stride + p;
+        gp.grad[g] += -((um - T(2) * u0 + up) * k.inv_dt2) * uc;
+        if (gp.illum) {
+            T add = u0 * u0;
+            if (gp.first) add += up * up;
+            gp.illum[g] += add;
+        }
+    }
+}
+
+template <typename T, int R, int ND>
+static int launch_step_rnd(const Plan &p, const StepConsts<T> &k, const StepPtrs<T> &sp, const GradPtrs<T> &gp,
+                           int nshots)
+{
+    dim3 block(64, 4, 1);
+    dim3 grid((k.n2 + 63) / 64, (k.n1 + 3) / 4, (unsigned)(nshots * k.n0));
+    if (gp.um)
+        hipLaunchKernelGGL((step_generic_kernel<T, R, ND, true>), grid, block, 0, p.stream, k, sp, gp);
+    else
+        hipLaunchKernelGGL((step_generic_kernel<T, R, ND, false>), grid, block, 0, p.stream, k, sp, gp);
+    MIFWI_HIP(hipGetLastError());
+    return MIFWI_OK;
+}
+
+template <typename T, int R>
+static int launch_step_r(const Plan &p, const StepConsts<T> &k, const StepPtrs<T> &sp, const GradPtrs<T> &gp,
+                         int nshots)
+{
+    switch (p.L.ndim) {
+        case 1: return launch_step_rnd<T, R, 1>(p, k, sp, gp, nshots);
+        case 2: return launch_step_rnd<T, R, 2>(p, k, sp, gp, nshots);
+        default: return launch_step_rnd<T, R, 3>(p, k, sp, gp, nshots);
+    }
+}
+
+template <typename T>
+int launch_step_generic(const Plan &p, const StepConsts<T> &k, const StepPtrs<T> &sp, const GradPtrs<T> &gp,
+                        int nshots)
+{
+    if ((long)nshots * k.n0 > 65535) {
+        set_error("generic kernel: nshots * shape[0] exceeds the grid z limit");
+        return MIFWI_EINVAL;
+    }
+    switch (p.L.R) {
+        case 1: return launch_step_r<T, 1>(p, k, sp, gp, nshots);
+        case 2: return launch_step_r<T, 2>(p, k, sp, gp, nshots);
+        case 3: return launch_step_r<T, 3>(p, k, sp, gp, nshots);
+        case 4: return launch_step_r<T, 4>(p, k, sp, gp, nshots);
+        case 5: return launch_step_r<T, 5>(p, k, sp, gp, nshots);
+        case 6: return launch_step_r<T, 6>(p, k, sp, gp, nshots);
+        case 7: return launch_step_r<T, 7>(p, k, sp, gp, nshots);
+        case 8: return launch_step_r<T, 8>(p, k, sp, gp, nshots);
+    }
+    set_error("unsupported stencil radius");
+    return MIFWI_EINVAL;
+}
+template int launch_step_generic<float>(const Plan &, const StepConsts<float> &, const StepPtrs<float> &,
+                                        const GradPtrs<float> &, int);
+template int launch_step_generic<double>(const Plan &, const StepConsts<double> &, const StepPtrs<double> &,
+                                         const GradPtrs<double> &, int);
+
+// ------------------------------------------------------------------------------------------
+// Sparse operations of one time step (seismic/acoustic/operators.py:134,137,173,176,221).
+// blockIdx.y = shot.  Blocks [0, nb_inj) inject, blocks [nb_inj, nb_inj + nb_itp) interpolate.
+// ------------------------------------------------------------------------------------------
+template <typename T>
+struct SparseDev {
+    // injection
+    const int32_t *uc_cell, *uc_ptr, *uc_count, *e_point;
+    const T *e_w;
+    int inj_kmax, inj_npoint, inj_per_shot, nb_inj;
+    T *field_inj;
+    const T *vals_inj;
+    // interpolation
+    const int32_t *pt_idx;
+    const T *pt_w;
+    int itp_npoint, itp_ncorner, itp_per_shot;
+    const T *field_int;
+    T *vals_out;
+    long shot_stride;
+    const T *m;
+    int time, nt;
+    T dt2;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void sparse_kernel(SparseDev<T> d)
+{
+    const int shot = blockIdx.y;
+    if ((int)blockIdx.x < d.nb_inj) {
+        const int tab = d.inj_per_shot ? shot : 0;
+        const int kk = blockIdx.x * 256 + threadIdx.x;
+        if (kk >= d.uc_count[tab]) return;
+        const int32_t *ptr = d.uc_ptr + (long)tab * (d.inj_kmax + 1);
+        const int32_t *ep = d.e_point + (long)tab * d.inj_kmax;
+        const T *ew = d.e_w + (long)tab * d.inj_kmax;
+        const T *vals = d.vals_inj + ((long)shot * d.nt + d.time) * d.inj_npoint;
+        T sum = 0;
+        for (int e = ptr[kk]; e < ptr[kk + 1]; ++e) sum += ew[e] * vals[ep[e]];
+        const long cell = d.uc_cell[(long)tab * d.inj_kmax + kk];
+        d.field_inj[(long)shot * d.shot_stride + cell] += sum * d.dt2 / d.m[cell];
+    } else {
+        const int tab = d.itp_per_shot ? shot : 0;
+        const int pnt = (blockIdx.x - d.nb_inj) * 256 + threadIdx.x;
+        if (pnt >= d.itp_npoint) return;
+        const int32_t *idx = d.pt_idx + ((long)tab * d.itp_npoint + pnt) * d.itp_ncorner;
+        const T *w = d.pt_w + ((long)tab * d.itp_npoint + pnt) * d.itp_ncorner;
+        const T *f = d.field_int + (long)shot * d.shot_stride;
+        T sum = 0;
+        for (int c = 0; c < d.itp_ncorner; ++c) sum += w[c] * f[idx[c]];
+        d.vals_out[((long)shot * d.nt + d.time) * d.itp_npoint + pnt] = sum;
+    }
+}
+
+template <typename T>
+int launch_sparse(const Plan &p, const SparsePtrs<T> &sp, int nshots)
+{
+    SparseDev<T> d{};
+    d.nb_inj = 0;
+    int nb_itp = 0;
+    if (sp.inj && sp.inj->npoint > 0 && sp.inj->max_count > 0) {
+        d.uc_cell = sp.inj->uc_cell;
+        d.uc_ptr = sp.inj->uc_ptr;
+        d.uc_count = sp.inj->uc_count;
+        d.e_point = sp.inj->e_point;
+        d.e_w = (const T *)sp.inj->e_w;
+        d.inj_kmax = sp.inj->kmax;
+        d.inj_npoint = sp.inj->npoint;
+        d.inj_per_shot = sp.inj->per_shot;
+        d.nb_inj = (sp.inj->max_count + 255) / 256;
+        d.field_inj = sp.field_inj;
+        d.vals_inj = sp.vals_inj;
+    }
+    if (sp.itp && sp.itp->npoint > 0) {
+        d.pt_idx = sp.itp->pt_idx;
+        d.pt_w = (const T *)sp.itp->pt_w;
+        d.itp_npoint = sp.itp->npoint;
+        d.itp_ncorner = sp.itp->ncorner;
+        d.itp_per_shot = sp.itp->per_shot;
+        d.field_int = sp.field_int;
+        d.vals_out = sp.vals_out;
+        nb_itp = (sp.itp->npoint + 255) / 256;
+    }
+    if (d.nb_inj + nb_itp == 0) return MIFWI_OK;
+    d.shot_stride = sp.shot_stride;
+    d.m = sp.m;
+    d.time = sp.time;
+    d.nt = sp.nt;
+    d.dt2 = sp.dt2;
+    hipLaunchKernelGGL((sparse_kernel<T>), dim3(d.nb_inj + nb_itp, nshots), dim3(256), 0, p.stream, d);
+    MIFWI_HIP(hipGetLastError());
+    return MIFWI_OK;
+}
+template int launch_sparse<float>(const Plan &, const SparsePtrs<float> &, int);
+template int launch_sparse<double>(const Plan &, const SparsePtrs<double> &, int);
+
+// ------------------------------------------------------------------------------------------
+// dense <-> haloed copies and model preparation
+// ------------------------------------------------------------------------------------------
+struct DenseMap {
+    int n0, n1, n2;
+    long s0, s1, off0, ngrid;
+};
+static DenseMap dense_map(const Layout &L)
+{
+    return DenseMap{L.n[0], L.n[1], L.n[2], L.s0, L.s1, L.off0, L.ngrid};
+}
+__device__ inline long halo_index(const DenseMap &d, long g)
+{
+    const int i2 = (int)(g % d.n2);
+    const long r = g / d.n2;
+    const int i1 = (int)(r % d.n1);
+    const int i0 = (int)(r / d.n1);
+    return d.off0 + (long)i0 * d.s0 + (long)i1 * d.s1 + i2;
+}
+
+template <typename T>
+__global__ void prep_model_kernel(DenseMap d, const T *vp, const T *damp, T *m, T *eta)
+{
+    for (long g = blockIdx.x * (long)blockDim.x + threadIdx.x; g < d.ngrid; g += (long)gridDim.x * blockDim.x) {
+        const long h = halo_index(d, g);
+        const T v = vp[g];
+        m[h] = T(1) / (v * v);  // seismic/model.py:395-400
+        eta[h] = damp ? damp[g] : T(0);
+    }
+}
+template <typename T>
+int launch_prep_model(const Plan &p, const T *vp, const T *damp, T *m, T *eta)
+{
+    const int nb = (int)((p.L.ngrid + 255) / 256 < 4096 ? (p.L.ngrid + 255) / 256 : 4096);
+    hipLaunchKernelGGL((prep_model_kernel<T>), dim3(nb), dim3(256), 0, p.stream, dense_map(p.L), vp, damp, m, eta);
+    MIFWI_HIP(hipGetLastError());
+    return MIFWI_OK;
+}
+template int launch_prep_model<float>(const Plan &, const float *, const float *, float *, float *);
+template int launch_prep_model<double>(const Plan &, const double *, const double *, double *, double *);
+
+template <typename T, int MODE>
+__global__ void unpack_kernel(DenseMap d, const T *haloed, long shot_stride, T *dense)
+{
+    const int shot = blockIdx.y;
+    for (long g = blockIdx.x * (long)blockDim.x + threadIdx.x; g < d.ngrid; g += (long)gridDim.x * blockDim.x) {
+        const T v = haloed[(long)shot * shot_stride + halo_index(d, g)];
+        if (MODE == 0) dense[(long)shot * d.ngrid + g] = v;
+        else dense[(long)shot * d.ngrid + g] += v;
+    }
+}
+template <typename T>
+int launch_unpack(const Plan &p, const T *haloed, long shot_stride, T *dense, int nshots, int mode)
+{
+    const int nb = (int)((p.L.ngrid + 255) / 256 < 4096 ? (p.L.ngrid + 255) / 256 : 4096);
+    if (mode == 0)
+        hipLaunchKernelGGL((unpack_kernel<T, 0>), dim3(nb, nshots), dim3(256), 0, p.stream, dense_map(p.L), haloed,
+                           shot_stride, dense);
+    else
+        hipLaunchKernelGGL((unpack_kernel<T, 1>), dim3(nb, nshots), dim3(256), 0, p.stream, dense_map(p.L), haloed,
+                           shot_stride, dense);
+    MIFWI_HIP(hipGetLastError());
+    return MIFWI_OK;
+}
+template int launch_unpack<float>(const Plan &, const float *, long, float *, int, int);
+template int launch_unpack<double>(const Plan &, const double *, long, double *, int, int);
+
+template <typename T>
+__global__ void pack_kernel(DenseMap d, const T *dense, T *haloed, long shot_stride)
+{
+    const int shot = blockIdx.y;
+    for (long g = blockIdx.x * (long)blockDim.x + threadIdx.x; g < d.ngrid; g += (long)gridDim.x * blockDim.x)
+        haloed[(long)shot * shot_stride + halo_index(d, g)] = dense[(long)shot * d.ngrid + g];
+}
+template <typename T>
+int launch_pack(const Plan &p, const T *dense, T *haloed, long shot_stride, int nshots)
+{
+    const int nb = (int)((p.L.ngrid + 255) / 256 < 4096 ? (p.L.ngrid + 255) / 256 : 4096);
+    hipLaunchKernelGGL((pack_kernel<T>), dim3(nb, nshots), dim3(256), 0, p.stream, dense_map(p.L), dense, haloed,
+                       shot_stride);
+    MIFWI_HIP(hipGetLastError());
+    return MIFWI_OK;
+}
+template int launch_pack<float>(const Plan &, const float *, float *, long, int);
+template int launch_pack<double>(const Plan &, const double *, double *, long, int);
+
+// ------------------------------------------------------------------------------------------
+// L2 misfit (misfit/misfit.py:5-9): residual = syn - obs, fval = 0.5 * ||residual||^2.
+// Deterministic: fixed block partition, tree reduction in f64, then one block per shot sums the
+// partials in index order.
+// ------------------------------------------------------------------------------------------
+constexpr int kMisfitBlocks = 64;
+
+template <typename T>
+__global__ __launch_bounds__(256) void misfit_partial_kernel(const T *syn, const T *obs, T *res, long n, double *partial)
+{
+    __shared__ double red[256];
+    const int shot = blockIdx.y;
+    const T *s = syn + (long)shot * n;
+    const T *o = obs + (long)shot * n;
+    T *r = res + (long)shot * n;
+    double acc = 0.0;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += 256L * kMisfitBlocks) {
+        const T d = s[i] - o[i];
+        r[i] = d;
+        acc += (double)d * (double)d;
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[shot * kMisfitBlocks + blockIdx.x] = red[0];
+}
+__global__ void misfit_final_kernel(const double *partial, double *fval)
+{
+    const int shot = blockIdx.x;
+    if (threadIdx.x == 0) {
+        double s = 0.0;
+        for (int b = 0; b < kMisfitBlocks; ++b) s += partial[shot * kMisfitBlocks + b];
+        fval[shot] = 0.5 * s;
+    }
+}
+template <typename T>
+int launch_l2_misfit(const Plan &p, const T *syn, const T *obs, T *res, long n, int nshots, double *partial,
+                     double *fval)
+{
+    hipLaunchKernelGGL((misfit_partial_kernel<T>), dim3(kMisfitBlocks, nshots), dim3(256), 0, p.stream, syn, obs, res,
+                       n, partial);
+    MIFWI_HIP(hipGetLastError());
+    hipLaunchKernelGGL(misfit_final_kernel, dim3(nshots), dim3(64), 0, p.stream, partial, fval);
+    MIFWI_HIP(hipGetLastError());
+    return MIFWI_OK;
+}
+template int launch_l2_misfit<float>(const Plan &, const float *, const float *, float *, long, int, double *,
+                                     double *);
+template int launch_l2_misfit<double>(const Plan &, const double *, const double *, double *, long, int, double *,
+                                      double *);
+
+}  // namespace mifwi

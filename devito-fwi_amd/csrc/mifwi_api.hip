@@ -1,0 +1,844 @@
+// Host side of libmifwi: the extern "C" entry points of include/mifwi.h, plan/device-memory
+// management, sparse geometry tables and the time loops that drive the HIP kernels.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <new>
+
+#include "mifwi_internal.hpp"
+
+namespace mifwi {
+
+static thread_local std::string g_error;
+void set_error(const std::string &msg) { g_error = msg; }
+
+static int fail(int code, const std::string &msg)
+{
+    set_error(msg);
+    return code;
+}
+
+// Centred 2nd-derivative weights on -R..R in closed form:
+//   w_k = 2 (-1)^(k+1) (R!)^2 / (k^2 (R-k)! (R+k)!),  w_0 = -2 sum_k w_k
+// (the values of sympy.finite_diff_weights(2, range(-R,R+1), 0)[-1][-1] that Devito's `.laplace`
+// uses, seismic/acoustic/operators.py:56).
+static void fd2_weights(int R, double *w)
+{
+    double s = 0.0;
+    for (int k = 1; k <= R; ++k) {
+        // (R!)^2 / ((R-k)! (R+k)!) = prod_{j=1..k} (R-k+j)/(R+j)
+        double q = 1.0;
+        for (int j = 1; j <= k; ++j) q *= (double)(R - k + j) / (double)(R + j);
+        w[k] = ((k & 1) ? 2.0 : -2.0) * q / ((double)k * (double)k);
+        s += w[k];
+    }
+    w[0] = -2.0 * s;
+}
+
+static long round_up(long v, long m) { return (v + m - 1) / m * m; }
+
+static int make_layout(const mifwi_config &c, Layout &L)
+{
+    L = Layout{};
+    L.ndim = c.ndim;
+    L.R = c.space_order / 2;
+    for (int d = 0; d < c.ndim; ++d) {
+        const int k = 3 - c.ndim + d;
+        L.n[k] = c.shape[d];
+        L.act[k] = 1;
+        L.halo[k] = L.R;
+    }
+    L.zl = (int)round_up(L.R, 4);
+    const long pitch = round_up((long)L.zl + round_up(L.n[2], 4) + L.zl, 32);
+    L.s1 = pitch;
+    L.s0 = pitch * (L.n[1] + 2 * L.halo[1]);
+    const long body = L.s0 * (L.n[0] + 2 * L.halo[0]);
+    const long first = (long)L.halo[0] * L.s0 + (long)L.halo[1] * L.s1 + L.zl;  // unshifted index of (0,0,0)
+    const long shift = (32 - first % 32) % 32;
+    L.off0 = first + shift;
+    // one extra row of slack so that vector reads that start inside the right z halo of the
+    // last row stay inside the allocation
+    L.field = round_up(body + shift + 64, 32);
+    L.ngrid = (long)L.n[0] * L.n[1] * L.n[2];
+    if (L.field > 0x7fffffffL) return -1;  // sparse tables use 32-bit offsets
+    return 0;
+}
+
+template <typename T>
+static StepConsts<T> make_consts(const Plan &p)
+{
+    StepConsts<T> k{};
+    double w[kMaxR + 1];
+    fd2_weights(p.L.R, w);
+    double c0 = 0.0;
+    for (int d = 0; d < p.cfg.ndim; ++d) {
+        const int kd = 3 - p.cfg.ndim + d;
+        const double ih2 = 1.0 / (p.cfg.spacing[d] * p.cfg.spacing[d]);
+        c0 += w[0] * ih2;
+        for (int j = 0; j <= p.L.R; ++j) k.c[kd][j] = (T)(w[j] * ih2);
+    }
+    k.c0 = (T)c0;
+    k.dt = (T)p.cfg.dt;
+    k.dt2 = k.dt * k.dt;
+    k.inv_dt2 = T(1) / k.dt2;
+    k.n0 = p.L.n[0];
+    k.n1 = p.L.n[1];
+    k.n2 = p.L.n[2];
+    k.s0 = p.L.s0;
+    k.s1 = p.L.s1;
+    k.off0 = p.L.off0;
+    k.field = p.L.field;
+    return k;
+}
+
+// ---- device memory helpers ------------------------------------------------------------------
+static int dev_alloc(Plan &p, void **ptr, size_t bytes, bool zero)
+{
+    *ptr = nullptr;
+    if (bytes == 0) bytes = 256;
+    hipError_t e = hipMalloc(ptr, bytes);
+    if (e != hipSuccess) {
+        set_error(std::string("hipMalloc of ") + std::to_string(bytes) + " bytes: " + hipGetErrorString(e));
+        (void)hipGetLastError();
+        return MIFWI_ENOMEM;
+    }
+    p.device_bytes += (int64_t)bytes;
+    if (zero) MIFWI_HIP(hipMemsetAsync(*ptr, 0, bytes, p.stream));
+    return MIFWI_OK;
+}
+static void dev_free(void *ptr)
+{
+    if (ptr) (void)hipFree(ptr);
+}
+
+static void free_sparse(SparseSet &s)
+{
+    dev_free(s.pt_idx);
+    dev_free(s.pt_w);
+    dev_free(s.uc_cell);
+    dev_free(s.uc_ptr);
+    dev_free(s.uc_count);
+    dev_free(s.e_point);
+    dev_free(s.e_w);
+    s = SparseSet{};
+}
+
+static void destroy(Plan *p)
+{
+    if (!p) return;
+    (void)hipSetDevice(p->device);
+    if (p->stream) (void)hipStreamSynchronize(p->stream);
+    dev_free(p->m);
+    dev_free(p->eta);
+    dev_free(p->rot_u);
+    dev_free(p->rot_v);
+    dev_free(p->saved);
+    free_sparse(p->src);
+    free_sparse(p->rec);
+    dev_free(p->d_wavelet);
+    dev_free(p->d_rec);
+    dev_free(p->d_res);
+    dev_free(p->d_srca);
+    dev_free(p->d_grad);
+    dev_free(p->d_illum);
+    dev_free(p->d_dense);
+    dev_free(p->d_partial);
+    dev_free(p->d_fval);
+    if (p->ev0) (void)hipEventDestroy(p->ev0);
+    if (p->ev1) (void)hipEventDestroy(p->ev1);
+    if (p->own_stream && p->stream) (void)hipStreamDestroy(p->stream);
+    delete p;
+}
+
+static int finish(Plan &p)
+{
+    if (!(p.cfg.flags & MIFWI_FLAG_ASYNC)) MIFWI_HIP(hipStreamSynchronize(p.stream));
+    return MIFWI_OK;
+}
+
+// copy `bytes` between any two of {host, device} pointers on the plan's stream
+static int copy_any(Plan &p, void *dst, const void *src, size_t bytes)
+{
+    if (bytes == 0) return MIFWI_OK;
+    MIFWI_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDefault, p.stream));
+    return MIFWI_OK;
+}
+
+static bool is_device_ptr(const void *ptr)
+{
+    hipPointerAttribute_t a{};
+    if (hipPointerGetAttributes(&a, ptr) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    return a.type == hipMemoryTypeDevice;
+}
+
+// ---- sparse tables --------------------------------------------------------------------------
+// Multilinear support of one point, in the arithmetic of the code Devito generates for
+// SparseTimeFunction.inject/interpolate (seismic/self_adjoint/sa_01_iso_implementation1.ipynb:
+// 1255-1316 of the reference): i = floor((x - o)/h), p = x - o - h*i, weights prod (1-p/h | p/h),
+// all in the grid dtype.  Corners outside the padded grid only ever meet zero field values (halo)
+// and zero velocity, so they are dropped here.
+template <typename T>
+static int build_sparse(Plan &p, SparseSet &S, const T *coords /* [tables][npoint][ndim] host */, int npoint,
+                        int tables, int per_shot)
+{
+    free_sparse(S);
+    const Layout &L = p.L;
+    const int nd = L.ndim, nc = 1 << nd;
+    S.npoint = npoint;
+    S.ncorner = nc;
+    S.per_shot = per_shot;
+    S.nshots = tables;
+    S.kmax = std::max(1, npoint * nc);
+    std::vector<int32_t> pt_idx((size_t)tables * npoint * nc, (int32_t)L.off0);
+    std::vector<T> pt_w((size_t)tables * npoint * nc, T(0));
+    std::vector<int32_t> uc_cell((size_t)tables * S.kmax, (int32_t)L.off0), uc_ptr((size_t)tables * (S.kmax + 1), 0),
+        uc_count(tables, 0), e_point((size_t)tables * S.kmax, 0);
+    std::vector<T> e_w((size_t)tables * S.kmax, T(0));
+    struct Entry {
+        int32_t cell;
+        int32_t point;
+        int32_t corner;
+        T w;
+    };
+    std::vector<Entry> ent;
+    S.max_count = 0;
+    for (int t = 0; t < tables; ++t) {
+        ent.clear();
+        for (int q = 0; q < npoint; ++q) {
+            int i[3] = {0, 0, 0};
+            T f[3] = {0, 0, 0};
+            for (int d = 0; d < nd; ++d) {
+                const int k = 3 - nd + d;
+                const T h = (T)p.cfg.spacing[d], o = (T)p.cfg.origin[d];
+                const T pos = coords[((size_t)t * npoint + q) * nd + d] - o;
+                const T fl = std::floor(pos / h);
+                if (!(std::fabs((double)fl) < 1e9)) return fail(MIFWI_EINVAL, "non-finite or absurd sparse coordinate");
+                i[k] = (int)fl;
+                f[k] = (pos - h * fl) / h;
+            }
+            for (int b = 0; b < nc; ++b) {
+                int j[3] = {0, 0, 0};
+                T w = 1;
+                bool ok = true;
+                for (int d = 0; d < nd; ++d) {
+                    const int k = 3 - nd + d;
+                    const int up = (b >> (nd - 1 - d)) & 1;
+                    j[k] = i[k] + up;
+                    w *= up ? f[k] : (T(1) - f[k]);
+                    if (j[k] < 0 || j[k] >= L.n[k]) ok = false;
+                }
+                if (!ok) continue;
+                const long cell = L.off0 + (long)j[0] * L.s0 + (long)j[1] * L.s1 + j[2];
+                pt_idx[((size_t)t * npoint + q) * nc + b] = (int32_t)cell;
+                pt_w[((size_t)t * npoint + q) * nc + b] = w;
+                ent.push_back(Entry{(int32_t)cell, q, b, w});
+            }
+        }
+        std::sort(ent.begin(), ent.end(), [](const Entry &a, const Entry &b) {
+            if (a.cell != b.cell) return a.cell < b.cell;
+            if (a.point != b.point) return a.point < b.point;
+            return a.corner < b.corner;
+        });
+        int nu = 0;
+        int32_t *cellp = &uc_cell[(size_t)t * S.kmax];
+        int32_t *ptrp = &uc_ptr[(size_t)t * (S.kmax + 1)];
+        for (size_t e = 0; e < ent.size(); ++e) {
+            if (e == 0 || ent[e].cell != ent[e - 1].cell) {
+                cellp[nu] = ent[e].cell;
+                ptrp[nu] = (int32_t)e;
+                ++nu;
+            }
+            e_point[(size_t)t * S.kmax + e] = ent[e].point;
+            e_w[(size_t)t * S.kmax + e] = ent[e].w;
+        }
+        ptrp[nu] = (int32_t)ent.size();
+        uc_count[t] = nu;
+        S.max_count = std::max(S.max_count, nu);
+    }
+    int rc;
+    auto up = [&](void **dst, const void *src, size_t bytes) -> int {
+        if ((rc = dev_alloc(p, dst, bytes, false))) return rc;
+        MIFWI_HIP(hipMemcpyAsync(*dst, src, bytes, hipMemcpyHostToDevice, p.stream));
+        return MIFWI_OK;
+    };
+    if ((rc = up((void **)&S.pt_idx, pt_idx.data(), pt_idx.size() * 4))) return rc;
+    if ((rc = up(&S.pt_w, pt_w.data(), pt_w.size() * sizeof(T)))) return rc;
+    if ((rc = up((void **)&S.uc_cell, uc_cell.data(), uc_cell.size() * 4))) return rc;
+    if ((rc = up((void **)&S.uc_ptr, uc_ptr.data(), uc_ptr.size() * 4))) return rc;
+    if ((rc = up((void **)&S.uc_count, uc_count.data(), uc_count.size() * 4))) return rc;
+    if ((rc = up((void **)&S.e_point, e_point.data(), e_point.size() * 4))) return rc;
+    if ((rc = up(&S.e_w, e_w.data(), e_w.size() * sizeof(T)))) return rc;
+    // the host vectors die at return: make sure the uploads have been consumed
+    MIFWI_HIP(hipStreamSynchronize(p.stream));
+    return MIFWI_OK;
+}
+
+// ---- plan -------------------------------------------------------------------------------------
+static int validate(const mifwi_config &c)
+{
+    if (c.ndim < 1 || c.ndim > 3) return fail(MIFWI_EINVAL, "ndim must be 1, 2 or 3");
+    if (c.space_order < 2 || c.space_order > 2 * kMaxR || (c.space_order & 1))
+        return fail(MIFWI_EINVAL, "space_order must be even and in 2..16");
+    for (int d = 0; d < c.ndim; ++d) {
+        if (c.shape[d] < 1) return fail(MIFWI_EINVAL, "shape entries must be positive");
+        if (!(c.spacing[d] > 0.0)) return fail(MIFWI_EINVAL, "spacing entries must be positive");
+    }
+    if (c.nt < 3) return fail(MIFWI_EINVAL, "nt must be at least 3");
+    if (!(c.dt > 0.0)) return fail(MIFWI_EINVAL, "dt must be positive");
+    if (c.dtype != MIFWI_F32 && c.dtype != MIFWI_F64) return fail(MIFWI_EINVAL, "dtype must be MIFWI_F32 or MIFWI_F64");
+    if (c.nsrc < 0 || c.nrec < 0) return fail(MIFWI_EINVAL, "nsrc/nrec must be non-negative");
+    if (c.max_shots < 1) return fail(MIFWI_EINVAL, "max_shots must be at least 1");
+    return MIFWI_OK;
+}
+
+static int create(const mifwi_config *cfg, mifwi_plan **out)
+{
+    if (!cfg || !out) return fail(MIFWI_EINVAL, "null argument");
+    *out = nullptr;
+    int rc = validate(*cfg);
+    if (rc) return rc;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) {
+        (void)hipGetLastError();
+        return fail(MIFWI_ENODEV, "no HIP device available (this library has no CPU path)");
+    }
+    int dev = cfg->device;
+    if (dev < 0) MIFWI_HIP(hipGetDevice(&dev));
+    if (dev >= ndev) return fail(MIFWI_EINVAL, "device ordinal out of range");
+    MIFWI_HIP(hipSetDevice(dev));
+    Plan *p = new (std::nothrow) Plan();
+    if (!p) return fail(MIFWI_ENOMEM, "host allocation failed");
+    p->cfg = *cfg;
+    p->device = dev;
+    p->esize = cfg->dtype == MIFWI_F64 ? 8 : 4;
+    if (make_layout(*cfg, p->L)) {
+        delete p;
+        return fail(MIFWI_EINVAL, "grid too large for 32-bit sparse offsets");
+    }
+    auto bail = [&](int code) {
+        destroy(p);
+        return code;
+    };
+    if (hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking) != hipSuccess)
+        return bail(fail(MIFWI_EHIP, "hipStreamCreate failed"));
+    p->own_stream = true;
+    if (hipEventCreate(&p->ev0) != hipSuccess || hipEventCreate(&p->ev1) != hipSuccess)
+        return bail(fail(MIFWI_EHIP, "hipEventCreate failed"));
+    const size_t es = p->esize;
+    const size_t field = (size_t)p->L.field;
+    const size_t S = (size_t)cfg->max_shots;
+    const size_t nt = (size_t)cfg->nt;
+    if ((rc = dev_alloc(*p, &p->m, field * es, true))) return bail(rc);
+    if ((rc = dev_alloc(*p, &p->eta, field * es, true))) return bail(rc);
+    if ((rc = dev_alloc(*p, &p->rot_u, S * 3 * field * es, true))) return bail(rc);
+    if ((rc = dev_alloc(*p, &p->rot_v, S * 3 * field * es, true))) return bail(rc);
+    if ((rc = dev_alloc(*p, &p->d_wavelet, S * nt * std::max(1, cfg->nsrc) * es, true))) return bail(rc);
+    if ((rc = dev_alloc(*p, &p->d_srca, S * nt * std::max(1, cfg->nsrc) * es, true))) return bail(rc);
+    if ((rc = dev_alloc(*p, &p->d_rec, S * nt * std::max(1, cfg->nrec) * es, true))) return bail(rc);
+    if ((rc = dev_alloc(*p, &p->d_res, S * nt * std::max(1, cfg->nrec) * es, true))) return bail(rc);
+    p->dense_elems = std::max<size_t>(2, S) * (size_t)p->L.ngrid;
+    if ((rc = dev_alloc(*p, &p->d_dense, p->dense_elems * es, false))) return bail(rc);
+    if ((rc = dev_alloc(*p, (void **)&p->d_partial, S * 64 * sizeof(double), true))) return bail(rc);
+    if ((rc = dev_alloc(*p, (void **)&p->d_fval, S * sizeof(double), true))) return bail(rc);
+    if (hipStreamSynchronize(p->stream) != hipSuccess) return bail(fail(MIFWI_EHIP, "stream synchronize failed"));
+    *out = reinterpret_cast<mifwi_plan *>(p);
+    return MIFWI_OK;
+}
+
+template <typename T>
+static int set_model(Plan &p, const void *vp, const void *damp)
+{
+    const size_t bytes = (size_t)p.L.ngrid * sizeof(T);
+    T *dvp = (T *)p.d_dense;
+    T *ddamp = dvp + p.L.ngrid;
+    int rc;
+    const T *vp_dev = (const T *)vp, *damp_dev = (const T *)damp;
+    if (!is_device_ptr(vp)) {
+        if ((rc = copy_any(p, dvp, vp, bytes))) return rc;
+        vp_dev = dvp;
+    }
+    if (damp && !is_device_ptr(damp)) {
+        if ((rc = copy_any(p, ddamp, damp, bytes))) return rc;
+        damp_dev = ddamp;
+    }
+    if ((rc = launch_prep_model<T>(p, vp_dev, damp_dev, (T *)p.m, (T *)p.eta))) return rc;
+    p.have_model = true;
+    // pageable host sources must not be reused by the caller before the copy has happened
+    MIFWI_HIP(hipStreamSynchronize(p.stream));
+    return MIFWI_OK;
+}
+
+template <typename T>
+static int set_geometry(Plan &p, int nshots, const void *src_coords, const void *rec_coords, int rec_per_shot)
+{
+    const int nd = p.cfg.ndim;
+    std::vector<T> sc((size_t)nshots * p.cfg.nsrc * nd), rc_((size_t)(rec_per_shot ? nshots : 1) * p.cfg.nrec * nd);
+    if (!sc.empty()) MIFWI_HIP(hipMemcpy(sc.data(), src_coords, sc.size() * sizeof(T), hipMemcpyDefault));
+    if (!rc_.empty()) MIFWI_HIP(hipMemcpy(rc_.data(), rec_coords, rc_.size() * sizeof(T), hipMemcpyDefault));
+    int rc;
+    if ((rc = build_sparse<T>(p, p.src, sc.data(), p.cfg.nsrc, nshots, 1))) return rc;
+    if ((rc = build_sparse<T>(p, p.rec, rc_.data(), p.cfg.nrec, rec_per_shot ? nshots : 1, rec_per_shot ? 1 : 0)))
+        return rc;
+    p.have_geometry = true;
+    p.geom_shots = nshots;
+    return MIFWI_OK;
+}
+
+static int check_run(Plan &p, int nshots)
+{
+    if (!p.have_model) return fail(MIFWI_ESTATE, "mifwi_set_model has not been called");
+    if (!p.have_geometry) return fail(MIFWI_ESTATE, "mifwi_set_geometry has not been called");
+    if (nshots < 1 || nshots > p.cfg.max_shots) return fail(MIFWI_EINVAL, "nshots must be in 1..max_shots");
+    if (nshots > p.geom_shots) return fail(MIFWI_EINVAL, "nshots exceeds the shots given to mifwi_set_geometry");
+    return MIFWI_OK;
+}
+
+static void fill_stats(Plan &p, double ms, double steps, int nshots, double bytes_per_point, int launches)
+{
+    p.stats.kernel_ms = ms;
+    p.stats.points = steps * (double)p.L.ngrid * nshots;
+    p.stats.gpointss = ms > 0 ? p.stats.points / (ms * 1e-3) / 1e9 : 0.0;
+    p.stats.algorithmic_bytes = p.stats.points * bytes_per_point * (p.esize / 4.0);
+    p.stats.launches = launches;
+    p.stats.kernel_kind = 0;
+    p.stats.device_bytes = p.device_bytes;
+}
+
+template <typename T>
+static int upload_wavelet(Plan &p, int nshots, const void *wavelet, int per_shot)
+{
+    const size_t one = (size_t)p.cfg.nt * p.cfg.nsrc * sizeof(T);
+    if (one == 0) return MIFWI_OK;
+    if (!wavelet) return fail(MIFWI_EINVAL, "wavelet is null");
+    int rc;
+    if (per_shot) return copy_any(p, p.d_wavelet, wavelet, one * nshots);
+    for (int s = 0; s < nshots; ++s)
+        if ((rc = copy_any(p, (char *)p.d_wavelet + s * one, wavelet, one))) return rc;
+    return MIFWI_OK;
+}
+
+// forward time loop on data already resident on the device (d_wavelet -> d_rec)
+template <typename T>
+static int run_forward(Plan &p, int nshots, int save)
+{
+    const Layout &L = p.L;
+    const int nt = p.cfg.nt;
+    int rc;
+    T *base;
+    long shot_stride;
+    if (save) {
+        if (!p.saved) {
+            const size_t bytes = (size_t)p.cfg.max_shots * nt * L.field * sizeof(T);
+            if ((rc = dev_alloc(p, &p.saved, bytes, true))) return rc;
+        }
+        base = (T *)p.saved;
+        shot_stride = (long)nt * L.field;
+        for (int s = 0; s < nshots; ++s)  // u[0] = u[1] = 0
+            MIFWI_HIP(hipMemsetAsync(base + s * shot_stride, 0, 2 * L.field * sizeof(T), p.stream));
+        p.saved_valid = false;
+    } else {
+        base = (T *)p.rot_u;
+        shot_stride = 3L * L.field;
+        MIFWI_HIP(hipMemsetAsync(base, 0, (size_t)nshots * shot_stride * sizeof(T), p.stream));
+        p.rot_u_valid = false;
+    }
+    MIFWI_HIP(hipMemsetAsync(p.d_rec, 0, (size_t)nshots * nt * p.cfg.nrec * sizeof(T), p.stream));
+    const StepConsts<T> k = make_consts<T>(p);
+    auto lvl = [&](int t) { return base + (long)(save ? t : t % 3) * L.field; };
+    MIFWI_HIP(hipEventRecord(p.ev0, p.stream));
+    int launches = 0;
+    for (int time = 1; time <= nt - 2; ++time) {
+        StepPtrs<T> sp{lvl(time), lvl(time - 1), lvl(time + 1), shot_stride, (const T *)p.m, (const T *)p.eta};
+        GradPtrs<T> gp{};
+        if ((rc = launch_step_generic<T>(p, k, sp, gp, nshots))) return rc;
+        SparsePtrs<T> q{};
+        q.inj = &p.src;
+        q.field_inj = lvl(time + 1);
+        q.vals_inj = (const T *)p.d_wavelet;
+        q.itp = &p.rec;
+        q.field_int = lvl(time);
+        q.vals_out = (T *)p.d_rec;
+        q.shot_stride = shot_stride;
+        q.m = (const T *)p.m;
+        q.time = time;
+        q.nt = nt;
+        q.dt2 = k.dt2;
+        if ((rc = launch_sparse<T>(p, q, nshots))) return rc;
+        launches += 2;
+    }
+    MIFWI_HIP(hipEventRecord(p.ev1, p.stream));
+    MIFWI_HIP(hipEventSynchronize(p.ev1));
+    float ms = 0;
+    MIFWI_HIP(hipEventElapsedTime(&ms, p.ev0, p.ev1));
+    fill_stats(p, ms, nt - 2, nshots, 20.0, launches);
+    if (save) {
+        p.saved_valid = true;
+        p.saved_shots = nshots;
+    } else {
+        p.rot_u_valid = true;
+    }
+    return MIFWI_OK;
+}
+
+// backward time loop: adjoint source in d_res; with_grad accumulates into d_grad/d_illum,
+// otherwise samples the field at the source positions into d_srca.
+template <typename T>
+static int run_backward(Plan &p, int nshots, bool with_grad, bool with_illum)
+{
+    const Layout &L = p.L;
+    const int nt = p.cfg.nt;
+    int rc;
+    T *base = (T *)p.rot_v;
+    const long shot_stride = 3L * L.field;
+    MIFWI_HIP(hipMemsetAsync(base, 0, (size_t)nshots * shot_stride * sizeof(T), p.stream));
+    p.rot_v_valid = false;
+    if (with_grad) {
+        if (!p.saved_valid || p.saved_shots < nshots)
+            return fail(MIFWI_ESTATE, "gradient needs the wavefield of a preceding forward(save=1) for these shots");
+        if (!p.d_grad && (rc = dev_alloc(p, &p.d_grad, (size_t)p.cfg.max_shots * L.field * sizeof(T), true))) return rc;
+        MIFWI_HIP(hipMemsetAsync(p.d_grad, 0, (size_t)nshots * L.field * sizeof(T), p.stream));
+        if (with_illum) {
+            if (!p.d_illum && (rc = dev_alloc(p, &p.d_illum, (size_t)p.cfg.max_shots * L.field * sizeof(T), true)))
+                return rc;
+            MIFWI_HIP(hipMemsetAsync(p.d_illum, 0, (size_t)nshots * L.field * sizeof(T), p.stream));
+        }
+    } else {
+        MIFWI_HIP(hipMemsetAsync(p.d_srca, 0, (size_t)nshots * nt * p.cfg.nsrc * sizeof(T), p.stream));
+    }
+    const StepConsts<T> k = make_consts<T>(p);
+    auto lvl = [&](int t) { return base + (long)((t + 3) % 3) * L.field; };
+    const T *sv = (const T *)p.saved;
+    const long sv_stride = (long)nt * L.field;
+    MIFWI_HIP(hipEventRecord(p.ev0, p.stream));
+    int launches = 0;
+    for (int time = nt - 2; time >= 1; --time) {
+        StepPtrs<T> sp{lvl(time), lvl(time + 1), lvl(time - 1), shot_stride, (const T *)p.m, (const T *)p.eta};
+        GradPtrs<T> gp{};
+        if (with_grad) {
+            gp.um = sv + (long)(time - 1) * L.field;
+            gp.uc = sv + (long)time * L.field;
+            gp.up = sv + (long)(time + 1) * L.field;
+            gp.u_shot_stride = sv_stride;
+            gp.grad = (T *)p.d_grad;
+            gp.illum = with_illum ? (T *)p.d_illum : nullptr;
+            gp.g_shot_stride = L.field;
+            gp.first = (time == nt - 2);
+        }
+        if ((rc = launch_step_generic<T>(p, k, sp, gp, nshots))) return rc;
+        SparsePtrs<T> q{};
+        q.inj = &p.rec;
+        q.field_inj = lvl(time - 1);
+        q.vals_inj = (const T *)p.d_res;
+        if (!with_grad) {
+            q.itp = &p.src;
+            q.field_int = lvl(time);
+            q.vals_out = (T *)p.d_srca;
+        }
+        q.shot_stride = shot_stride;
+        q.m = (const T *)p.m;
+        q.time = time;
+        q.nt = nt;
+        q.dt2 = k.dt2;
+        if ((rc = launch_sparse<T>(p, q, nshots))) return rc;
+        launches += 2;
+    }
+    MIFWI_HIP(hipEventRecord(p.ev1, p.stream));
+    MIFWI_HIP(hipEventSynchronize(p.ev1));
+    float ms = 0;
+    MIFWI_HIP(hipEventElapsedTime(&ms, p.ev0, p.ev1));
+    fill_stats(p, ms, nt - 2, nshots, with_grad ? 32.0 : 20.0, launches);
+    p.rot_v_valid = true;
+    return MIFWI_OK;
+}
+
+// deliver haloed per-shot fields (d_grad / d_illum) to a dense caller array
+template <typename T>
+static int deliver_grid(Plan &p, const void *haloed, void *user, int nshots, int accumulate)
+{
+    if (!user) return MIFWI_OK;
+    const size_t bytes = (size_t)nshots * p.L.ngrid * sizeof(T);
+    int rc;
+    if (is_device_ptr(user)) return launch_unpack<T>(p, (const T *)haloed, p.L.field, (T *)user, nshots, accumulate ? 1 : 0);
+    if ((size_t)nshots * p.L.ngrid > p.dense_elems) return fail(MIFWI_EINVAL, "internal staging buffer too small");
+    if (accumulate && (rc = copy_any(p, p.d_dense, user, bytes))) return rc;
+    if ((rc = launch_unpack<T>(p, (const T *)haloed, p.L.field, (T *)p.d_dense, nshots, accumulate ? 1 : 0))) return rc;
+    return copy_any(p, user, p.d_dense, bytes);
+}
+
+template <typename T>
+static int forward(Plan &p, int nshots, const void *wavelet, int per_shot, void *rec_out, int save)
+{
+    int rc;
+    if ((rc = check_run(p, nshots))) return rc;
+    if ((rc = upload_wavelet<T>(p, nshots, wavelet, per_shot))) return rc;
+    if ((rc = run_forward<T>(p, nshots, save))) return rc;
+    if (rec_out && (rc = copy_any(p, rec_out, p.d_rec, (size_t)nshots * p.cfg.nt * p.cfg.nrec * sizeof(T)))) return rc;
+    return finish(p);
+}
+
+template <typename T>
+static int adjoint(Plan &p, int nshots, const void *rec_in, void *srca_out)
+{
+    int rc;
+    if ((rc = check_run(p, nshots))) return rc;
+    if (!rec_in) return fail(MIFWI_EINVAL, "rec_in is null");
+    if ((rc = copy_any(p, p.d_res, rec_in, (size_t)nshots * p.cfg.nt * p.cfg.nrec * sizeof(T)))) return rc;
+    if ((rc = run_backward<T>(p, nshots, false, false))) return rc;
+    if (srca_out && (rc = copy_any(p, srca_out, p.d_srca, (size_t)nshots * p.cfg.nt * p.cfg.nsrc * sizeof(T)))) return rc;
+    return finish(p);
+}
+
+template <typename T>
+static int gradient(Plan &p, int nshots, const void *residual, void *grad, int accumulate, void *illum)
+{
+    int rc;
+    if ((rc = check_run(p, nshots))) return rc;
+    if (!residual || !grad) return fail(MIFWI_EINVAL, "residual or grad is null");
+    if ((rc = copy_any(p, p.d_res, residual, (size_t)nshots * p.cfg.nt * p.cfg.nrec * sizeof(T)))) return rc;
+    if ((rc = run_backward<T>(p, nshots, true, illum != nullptr))) return rc;
+    if ((rc = deliver_grid<T>(p, p.d_grad, grad, nshots, accumulate))) return rc;
+    if (illum && (rc = deliver_grid<T>(p, p.d_illum, illum, nshots, 0))) return rc;
+    return finish(p);
+}
+
+template <typename T>
+static int l2_misfit_gradient(Plan &p, int nshots, const void *wavelet, int per_shot, const void *obs, double *fval,
+                              void *grad, void *illum, void *residual_out, void *syn_out)
+{
+    int rc;
+    if ((rc = check_run(p, nshots))) return rc;
+    if (!obs) return fail(MIFWI_EINVAL, "obs is null");
+    const size_t dbytes = (size_t)nshots * p.cfg.nt * p.cfg.nrec * sizeof(T);
+    if ((rc = upload_wavelet<T>(p, nshots, wavelet, per_shot))) return rc;
+    double ms_total = 0, pts = 0, abytes = 0;
+    int launches = 0;
+    if ((rc = run_forward<T>(p, nshots, grad != nullptr))) return rc;
+    ms_total += p.stats.kernel_ms, pts += p.stats.points, abytes += p.stats.algorithmic_bytes, launches += p.stats.launches;
+    // observed data: use in place when already on the device, else stage it in d_res
+    const T *obs_dev = (const T *)obs;
+    if (!is_device_ptr(obs)) {
+        if ((rc = copy_any(p, p.d_res, obs, dbytes))) return rc;
+        obs_dev = (const T *)p.d_res;
+    }
+    if ((rc = launch_l2_misfit<T>(p, (const T *)p.d_rec, obs_dev, (T *)p.d_res, (long)p.cfg.nt * p.cfg.nrec, nshots,
+                                  p.d_partial, p.d_fval)))
+        return rc;
+    if (fval && (rc = copy_any(p, fval, p.d_fval, (size_t)nshots * sizeof(double)))) return rc;
+    if (syn_out && (rc = copy_any(p, syn_out, p.d_rec, dbytes))) return rc;
+    if (residual_out && (rc = copy_any(p, residual_out, p.d_res, dbytes))) return rc;
+    if (grad) {
+        if ((rc = run_backward<T>(p, nshots, true, illum != nullptr))) return rc;
+        ms_total += p.stats.kernel_ms, pts += p.stats.points, abytes += p.stats.algorithmic_bytes,
+            launches += p.stats.launches;
+        if ((rc = deliver_grid<T>(p, p.d_grad, grad, nshots, 0))) return rc;
+        if (illum && (rc = deliver_grid<T>(p, p.d_illum, illum, nshots, 0))) return rc;
+    }
+    p.stats.kernel_ms = ms_total;
+    p.stats.points = pts;
+    p.stats.algorithmic_bytes = abytes;
+    p.stats.gpointss = ms_total > 0 ? pts / (ms_total * 1e-3) / 1e9 : 0;
+    p.stats.launches = launches;
+    return finish(p);
+}
+
+template <typename T>
+static int read_wavefield(Plan &p, int which, int shot, int first, int count, void *out)
+{
+    if (!out) return fail(MIFWI_EINVAL, "out is null");
+    if (shot < 0 || shot >= p.cfg.max_shots) return fail(MIFWI_EINVAL, "shot out of range");
+    const T *base;
+    int nlev;
+    if (which == 0) {
+        if (!p.saved_valid || shot >= p.saved_shots) return fail(MIFWI_ESTATE, "no saved wavefield for this shot");
+        base = (const T *)p.saved + (long)shot * p.cfg.nt * p.L.field;
+        nlev = p.cfg.nt;
+    } else if (which == 1 || which == 2) {
+        if (!(which == 1 ? p.rot_u_valid : p.rot_v_valid)) return fail(MIFWI_ESTATE, "no buffered wavefield available");
+        base = (const T *)(which == 1 ? p.rot_u : p.rot_v) + (long)shot * 3 * p.L.field;
+        nlev = 3;
+    } else {
+        return fail(MIFWI_EINVAL, "which must be 0, 1 or 2");
+    }
+    if (first < 0 || count < 0 || first + count > nlev) return fail(MIFWI_EINVAL, "level range out of bounds");
+    int rc;
+    const bool dev = is_device_ptr(out);
+    // levels are consecutive fields: treat them as `count` "shots" of one level each
+    const int chunk = dev ? count : (int)std::max<size_t>(1, p.dense_elems / (size_t)p.L.ngrid);
+    for (int l = 0; l < count; l += chunk) {
+        const int n = std::min(chunk, count - l);
+        T *dst = (T *)out + (long)l * p.L.ngrid;
+        if (dev) {
+            if ((rc = launch_unpack<T>(p, base + (long)(first + l) * p.L.field, p.L.field, dst, n, 0))) return rc;
+        } else {
+            if ((rc = launch_unpack<T>(p, base + (long)(first + l) * p.L.field, p.L.field, (T *)p.d_dense, n, 0))) return rc;
+            if ((rc = copy_any(p, dst, p.d_dense, (size_t)n * p.L.ngrid * sizeof(T)))) return rc;
+            MIFWI_HIP(hipStreamSynchronize(p.stream));
+        }
+    }
+    return finish(p);
+}
+
+template <typename T>
+static int write_wavefield(Plan &p, int shot, int first, int count, const void *in)
+{
+    if (!in) return fail(MIFWI_EINVAL, "in is null");
+    if (shot < 0 || shot >= p.cfg.max_shots) return fail(MIFWI_EINVAL, "shot out of range");
+    if (first < 0 || count < 0 || first + count > p.cfg.nt) return fail(MIFWI_EINVAL, "level range out of bounds");
+    int rc;
+    if (!p.saved) {
+        const size_t bytes = (size_t)p.cfg.max_shots * p.cfg.nt * p.L.field * sizeof(T);
+        if ((rc = dev_alloc(p, &p.saved, bytes, true))) return rc;
+    }
+    T *base = (T *)p.saved + (long)shot * p.cfg.nt * p.L.field;
+    const bool dev = is_device_ptr(in);
+    const int chunk = dev ? count : (int)std::max<size_t>(1, p.dense_elems / (size_t)p.L.ngrid);
+    for (int l = 0; l < count; l += chunk) {
+        const int n = std::min(chunk, count - l);
+        const T *src = (const T *)in + (long)l * p.L.ngrid;
+        if (!dev) {
+            if ((rc = copy_any(p, p.d_dense, src, (size_t)n * p.L.ngrid * sizeof(T)))) return rc;
+            src = (const T *)p.d_dense;
+        }
+        if ((rc = launch_pack<T>(p, src, base + (long)(first + l) * p.L.field, p.L.field, n))) return rc;
+        if (!dev) MIFWI_HIP(hipStreamSynchronize(p.stream));
+    }
+    // a caller-provided field makes the shot usable by mifwi_gradient
+    p.saved_valid = true;
+    p.saved_shots = std::max(p.saved_shots, shot + 1);
+    return finish(p);
+}
+
+}  // namespace mifwi
+
+// =============================================================================================
+// C ABI
+// =============================================================================================
+using namespace mifwi;
+
+#define PLAN_OR_FAIL(plan)                                                     \
+    if (!(plan)) return fail(MIFWI_EINVAL, "plan is null");                    \
+    Plan &p = *reinterpret_cast<Plan *>(plan);                                 \
+    if (hipSetDevice(p.device) != hipSuccess) return fail(MIFWI_EHIP, "hipSetDevice failed")
+
+#define DISPATCH(expr_f32, expr_f64) (p.cfg.dtype == MIFWI_F64 ? (expr_f64) : (expr_f32))
+
+extern "C" {
+
+int mifwi_version(void) { return MIFWI_VERSION; }
+
+const char *mifwi_last_error(void) { return g_error.c_str(); }
+
+int mifwi_plan_create(const mifwi_config *cfg, mifwi_plan **out)
+{
+    try {
+        return create(cfg, out);
+    } catch (const std::exception &e) {
+        return fail(MIFWI_ENOMEM, std::string("exception: ") + e.what());
+    }
+}
+
+int mifwi_plan_destroy(mifwi_plan *plan)
+{
+    if (!plan) return MIFWI_OK;
+    destroy(reinterpret_cast<Plan *>(plan));
+    return MIFWI_OK;
+}
+
+int mifwi_set_stream(mifwi_plan *plan, void *hip_stream)
+{
+    PLAN_OR_FAIL(plan);
+    MIFWI_HIP(hipStreamSynchronize(p.stream));
+    if (p.own_stream && p.stream) (void)hipStreamDestroy(p.stream);
+    p.stream = reinterpret_cast<hipStream_t>(hip_stream);
+    p.own_stream = false;
+    return MIFWI_OK;
+}
+
+int mifwi_synchronize(mifwi_plan *plan)
+{
+    PLAN_OR_FAIL(plan);
+    MIFWI_HIP(hipStreamSynchronize(p.stream));
+    return MIFWI_OK;
+}
+
+int mifwi_set_model(mifwi_plan *plan, const void *vp, const void *damp)
+{
+    PLAN_OR_FAIL(plan);
+    if (!vp) return fail(MIFWI_EINVAL, "vp is null");
+    try {
+        return DISPATCH(set_model<float>(p, vp, damp), set_model<double>(p, vp, damp));
+    } catch (const std::exception &e) {
+        return fail(MIFWI_ENOMEM, std::string("exception: ") + e.what());
+    }
+}
+
+int mifwi_set_geometry(mifwi_plan *plan, int32_t nshots, const void *src_coords, const void *rec_coords,
+                       int32_t rec_per_shot)
+{
+    PLAN_OR_FAIL(plan);
+    if (nshots < 1 || nshots > p.cfg.max_shots) return fail(MIFWI_EINVAL, "nshots must be in 1..max_shots");
+    if ((p.cfg.nsrc > 0 && !src_coords) || (p.cfg.nrec > 0 && !rec_coords)) return fail(MIFWI_EINVAL, "null coordinates");
+    try {
+        return DISPATCH(set_geometry<float>(p, nshots, src_coords, rec_coords, rec_per_shot),
+                        set_geometry<double>(p, nshots, src_coords, rec_coords, rec_per_shot));
+    } catch (const std::exception &e) {
+        return fail(MIFWI_ENOMEM, std::string("exception: ") + e.what());
+    }
+}
+
+int mifwi_forward(mifwi_plan *plan, int32_t nshots, const void *wavelet, int32_t wavelet_per_shot, void *rec_out,
+                  int32_t save)
+{
+    PLAN_OR_FAIL(plan);
+    return DISPATCH(forward<float>(p, nshots, wavelet, wavelet_per_shot, rec_out, save),
+                    forward<double>(p, nshots, wavelet, wavelet_per_shot, rec_out, save));
+}
+
+int mifwi_adjoint(mifwi_plan *plan, int32_t nshots, const void *rec_in, void *srca_out)
+{
+    PLAN_OR_FAIL(plan);
+    return DISPATCH(adjoint<float>(p, nshots, rec_in, srca_out), adjoint<double>(p, nshots, rec_in, srca_out));
+}
+
+int mifwi_gradient(mifwi_plan *plan, int32_t nshots, const void *residual, void *grad, int32_t accumulate, void *illum)
+{
+    PLAN_OR_FAIL(plan);
+    return DISPATCH(gradient<float>(p, nshots, residual, grad, accumulate, illum),
+                    gradient<double>(p, nshots, residual, grad, accumulate, illum));
+}
+
+int mifwi_l2_misfit_gradient(mifwi_plan *plan, int32_t nshots, const void *wavelet, int32_t wavelet_per_shot,
+                             const void *obs, double *fval, void *grad, void *illum, void *residual_out, void *syn_out)
+{
+    PLAN_OR_FAIL(plan);
+    return DISPATCH(
+        l2_misfit_gradient<float>(p, nshots, wavelet, wavelet_per_shot, obs, fval, grad, illum, residual_out, syn_out),
+        l2_misfit_gradient<double>(p, nshots, wavelet, wavelet_per_shot, obs, fval, grad, illum, residual_out, syn_out));
+}
+
+int mifwi_read_wavefield(mifwi_plan *plan, int32_t which, int32_t shot, int32_t first, int32_t count, void *out)
+{
+    PLAN_OR_FAIL(plan);
+    return DISPATCH(read_wavefield<float>(p, which, shot, first, count, out),
+                    read_wavefield<double>(p, which, shot, first, count, out));
+}
+
+int mifwi_write_wavefield(mifwi_plan *plan, int32_t shot, int32_t first, int32_t count, const void *in)
+{
+    PLAN_OR_FAIL(plan);
+    return DISPATCH(write_wavefield<float>(p, shot, first, count, in), write_wavefield<double>(p, shot, first, count, in));
+}
+
+int mifwi_get_stats(mifwi_plan *plan, mifwi_stats *out)
+{
+    PLAN_OR_FAIL(plan);
+    if (!out) return fail(MIFWI_EINVAL, "out is null");
+    p.stats.device_bytes = p.device_bytes;
+    *out = p.stats;
+    return MIFWI_OK;
+}
+
+}  // extern "C"

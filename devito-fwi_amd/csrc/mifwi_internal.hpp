@@ -1,0 +1,179 @@
+// Internal declarations shared by the host side (plan management, geometry tables, time loops)
+// and the HIP kernels of libmifwi.  Not part of the public ABI (see include/mifwi.h).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "mifwi.h"
+
+namespace mifwi {
+
+constexpr int kMaxR = 8;        // space_order <= 16
+constexpr int kMaxCorners = 8;  // 2^ndim
+
+// ------------------------------------------------------------------------------------------
+// Device memory layout of one field level.
+//
+// A field is stored as a canonical 3-D array [n0+2h0][n1+2h1][pitch] (unused leading dims have
+// size 1 and no halo).  The last dimension is contiguous; grid point (i0,i1,i2) lives at
+//     off0 + i0*s0 + i1*s1 + i2
+// Halos of width R (zero, never written) surround the grid in every active dimension so that
+// stencil reads need no bounds checks.  The z halo on the left is rounded up to a multiple of 4
+// elements and the base is shifted so that off0 is a multiple of 32 elements: every grid row
+// then starts on a 128-byte boundary (f32) and 16-byte vector accesses along z are aligned.
+// ------------------------------------------------------------------------------------------
+struct Layout {
+    int ndim = 0;
+    int R = 0;
+    int n[3] = {1, 1, 1};
+    int act[3] = {0, 0, 0};
+    int halo[3] = {0, 0, 0};
+    int zl = 0;           // left z halo (multiple of 4, >= R)
+    long s0 = 0, s1 = 0;  // strides of canonical dims 0 and 1 (dim 2 has stride 1)
+    long off0 = 0;        // element index of grid point (0,0,0)
+    long field = 0;       // elements per field level (multiple of 32)
+    long ngrid = 0;       // n0*n1*n2
+};
+
+// Per-launch constants of the time-stepping kernels (passed by value).
+template <typename T>
+struct StepConsts {
+    T c0;                  // w_0 * sum_d 1/h_d^2
+    T c[3][kMaxR + 1];     // c[d][k] = w_k / h_d^2, canonical dims
+    T dt, dt2, inv_dt2;
+    int n0, n1, n2;
+    long s0, s1, off0;
+    long field;            // elements per level
+};
+
+// Sparse point set (sources or receivers) resident on the device.
+// Interpolation view: per point, kMaxCorners (index, weight) pairs (weight 0 for unused ones).
+// Injection view: CSR over the unique grid cells touched, so that each cell is updated by
+// exactly one thread, in a fixed order (deterministic, no atomics).
+struct SparseSet {
+    int npoint = 0;
+    int ncorner = 0;       // 2^ndim
+    int per_shot = 0;      // 0: one table shared by all shots
+    int nshots = 0;        // tables stored (1 if shared)
+    int kmax = 0;          // capacity of unique cells per shot = npoint*ncorner
+    // device arrays, [tables][...]
+    int32_t *pt_idx = nullptr;   // [tables][npoint][ncorner] element offsets (relative to level base)
+    void *pt_w = nullptr;        // [tables][npoint][ncorner] weights (T)
+    int32_t *uc_cell = nullptr;  // [tables][kmax]
+    int32_t *uc_ptr = nullptr;   // [tables][kmax+1]
+    int32_t *uc_count = nullptr; // [tables]
+    int32_t *e_point = nullptr;  // [tables][kmax]
+    void *e_w = nullptr;         // [tables][kmax] (T)
+    int max_count = 0;           // max unique cells over tables (host copy)
+};
+
+struct Plan {
+    mifwi_config cfg{};
+    Layout L{};
+    int device = 0;
+    size_t esize = 4;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+
+    void *m = nullptr, *eta = nullptr;       // haloed model fields
+    bool have_model = false;
+    bool have_geometry = false;
+    int geom_shots = 0;
+
+    void *rot_u = nullptr;                   // [max_shots][3][field] forward rotating buffers
+    void *rot_v = nullptr;                   // [max_shots][3][field] adjoint rotating buffers
+    void *saved = nullptr;                   // [max_shots][nt][field] saved forward field
+    bool saved_valid = false;
+    int saved_shots = 0;
+    bool rot_u_valid = false, rot_v_valid = false;
+
+    SparseSet src, rec;
+
+    void *d_wavelet = nullptr;               // [max_shots][nt][nsrc]
+    void *d_rec = nullptr;                   // [max_shots][nt][nrec]   synthetic data
+    void *d_res = nullptr;                   // [max_shots][nt][nrec]   adjoint source / residual
+    void *d_srca = nullptr;                  // [max_shots][nt][nsrc]
+    void *d_grad = nullptr, *d_illum = nullptr; // [max_shots][field] haloed accumulators
+    void *d_dense = nullptr;                 // dense staging, max(max_shots*ngrid, ...) elements
+    size_t dense_elems = 0;
+    double *d_partial = nullptr;             // misfit partial sums
+    double *d_fval = nullptr;                // [max_shots]
+
+    mifwi_stats stats{};
+    int64_t device_bytes = 0;
+};
+
+void set_error(const std::string &msg);
+
+#define MIFWI_HIP(call)                                                                            \
+    do {                                                                                           \
+        hipError_t e_ = (call);                                                                    \
+        if (e_ != hipSuccess) {                                                                    \
+            ::mifwi::set_error(std::string(#call) + ": " + hipGetErrorString(e_));                 \
+            return (e_ == hipErrorOutOfMemory) ? MIFWI_ENOMEM : MIFWI_EHIP;                        \
+        }                                                                                          \
+    } while (0)
+
+// ---- kernel launchers (kernels_generic.hip) ------------------------------------------------
+template <typename T>
+struct StepPtrs {
+    const T *cur;     // level being read with the stencil           (shot 0)
+    const T *old;     // level two steps away (centre point only)    (shot 0)
+    T *out;           // level being produced                         (shot 0)
+    long shot_stride; // elements between consecutive shots
+    const T *m, *eta;
+};
+
+template <typename T>
+struct GradPtrs {
+    const T *um, *uc, *up; // saved forward levels time-1, time, time+1 (shot 0); null = no gradient
+    long u_shot_stride;
+    T *grad;               // haloed accumulators (shot 0)
+    T *illum;              // or null
+    long g_shot_stride;
+    int first;             // 1 on the first backward step: also add u[time+1]^2 to illum
+};
+
+template <typename T>
+int launch_step_generic(const Plan &p, const StepConsts<T> &k, const StepPtrs<T> &sp,
+                        const GradPtrs<T> &gp, int nshots);
+
+// One launch doing both sparse operations of a time step:
+//   inject:  field_inj[cell] += (sum_e w_e * vals_inj[shot][time][point_e]) * dt2 / m[cell]
+//   interp:  vals_out[shot][time][p] = sum_c w_c * field_int[idx_c]
+template <typename T>
+struct SparsePtrs {
+    const SparseSet *inj;      // null: no injection
+    T *field_inj;              // shot 0 level base
+    const T *vals_inj;         // [shots][nt][inj->npoint]
+    const SparseSet *itp;      // null: no interpolation
+    const T *field_int;        // shot 0 level base
+    T *vals_out;               // [shots][nt][itp->npoint]
+    long shot_stride;
+    const T *m;
+    int time, nt;
+    T dt2;
+};
+template <typename T>
+int launch_sparse(const Plan &p, const SparsePtrs<T> &sp, int nshots);
+
+template <typename T>
+int launch_prep_model(const Plan &p, const T *vp_dense, const T *damp_dense, T *m, T *eta);
+
+// dense (nshots, grid) <-> haloed (nshots, field).  mode: 0 dst = src, 1 dst += src
+template <typename T>
+int launch_unpack(const Plan &p, const T *haloed, long shot_stride, T *dense, int nshots, int mode);
+template <typename T>
+int launch_pack(const Plan &p, const T *dense, T *haloed, long shot_stride, int nshots);
+
+// res = syn - obs ; fval[shot] = 0.5 * sum res^2 (f64, deterministic two-stage reduction)
+template <typename T>
+int launch_l2_misfit(const Plan &p, const T *syn, const T *obs, T *res, long n_per_shot, int nshots,
+                     double *partial, double *fval);
+
+}  // namespace mifwi

@@ -1,0 +1,7 @@
+"""
+ctypes binding of libmifwi.so, the MI355X-native acoustic propagator library
+(C ABI declared in include/mifwi.h).  There is no CPU fallback: importing works anywhere the
+shared library loads, but creating a plan without a GPU raises.
+"""
+from ._lib import (Plan, MifwiError, load_library, library_path, EXPORTED_SYMBOLS,  # noqa: F401
+                   F32, F64, FLAG_ASYNC, FLAG_NO_GRAPH, FLAG_GENERIC)

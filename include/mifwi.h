@@ -1,0 +1,165 @@
+/*
+ * mifwi -- MI355X-native isotropic acoustic propagators (forward / adjoint / gradient)
+ * for full-waveform inversion.  Plain C ABI: pointers, sizes, ints and doubles only.
+ *
+ * What this boundary replaces in the reference (LongyanU/devito-fwi).  The reference has no
+ * native propagator source of its own: seismic/acoustic/wavesolver.py:112,149,203 call
+ * `Operator.apply(...)` of Devito, which JIT-compiles a shared object and calls, through
+ * ctypes, one entry point per operator of the form
+ *     int Kernel(struct dataobj *damp_vec, const float dt, struct dataobj *vp_vec,
+ *                const float o_x, const float o_z, struct dataobj *rec_vec,
+ *                struct dataobj *rec_coords_vec, struct dataobj *src_vec,
+ *                struct dataobj *src_coords_vec, struct dataobj *u_vec,
+ *                const int x_M, const int x_m, ..., const int time_M, const int time_m,
+ *                struct profiler *timers)
+ * (shape recorded in seismic/self_adjoint/sa_01_iso_implementation1.ipynb:1187-1206).
+ * The entry points below are what a ctypes binding for that call site binds instead; each
+ * one names the reference call it stands in for.
+ *
+ * Conventions
+ *   - Every function returns 0 on success and a negative MIFWI_E* code on failure; the text of
+ *     the last failure on the calling thread is returned by mifwi_last_error().  Nothing
+ *     throws across the boundary.
+ *   - Grid arrays are C-ordered (first dimension slowest, last contiguous), cover the PADDED
+ *     grid (physical shape + 2*nbl per dimension) and carry NO halo: the library adds its own.
+ *   - Array arguments may be host pointers or device pointers of the plan's GPU (the library
+ *     copies with hipMemcpyDefault); they are borrowed for the duration of the call only.
+ *   - A plan owns all device memory it needs, including the saved forward wavefield, which stays
+ *     on the GPU between mifwi_forward(save=1) and mifwi_gradient().
+ *   - A plan is not re-entrant; calls on one plan are serialised by the caller.  Calls return
+ *     after the work has completed (they synchronise the plan's stream) unless
+ *     MIFWI_FLAG_ASYNC is set, in which case mifwi_synchronize() must precede any host read.
+ *   - There is no CPU fallback: without a usable HIP device mifwi_plan_create() fails.
+ */
+#ifndef MIFWI_H
+#define MIFWI_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MIFWI_VERSION 100
+
+enum {
+    MIFWI_OK = 0,
+    MIFWI_EINVAL = -1,   /* bad argument (shape, order, null pointer, shot count...)      */
+    MIFWI_EHIP = -2,     /* a HIP runtime call failed (text in mifwi_last_error)          */
+    MIFWI_ENOMEM = -3,   /* device allocation failed                                      */
+    MIFWI_ESTATE = -4,   /* call sequence error (e.g. gradient without a saved wavefield) */
+    MIFWI_ENODEV = -5    /* no usable GPU                                                 */
+};
+
+enum { MIFWI_F32 = 0, MIFWI_F64 = 1 };
+
+enum {
+    MIFWI_FLAG_ASYNC = 1,        /* do not synchronise at the end of each call            */
+    MIFWI_FLAG_NO_GRAPH = 2,     /* launch kernels one by one instead of replaying a graph */
+    MIFWI_FLAG_GENERIC = 4       /* force the untiled reference kernels                    */
+};
+
+typedef struct mifwi_plan mifwi_plan; /* opaque */
+
+/*
+ * Discretisation of one acquisition: what `SeismicModel` + `AcquisitionGeometry` +
+ * `AcousticWaveSolver.__init__` fix in the reference (seismic/model.py:91-124,
+ * seismic/utils.py:60-95, seismic/acoustic/wavesolver.py:28-46).
+ */
+typedef struct mifwi_config {
+    int32_t ndim;          /* 1, 2 or 3                                                    */
+    int32_t shape[3];      /* padded grid shape, shape[0..ndim)                            */
+    double spacing[3];     /* grid spacing per dimension (m)                               */
+    double origin[3];      /* coordinates of padded-grid point 0 (origin - nbl*spacing)    */
+    int32_t space_order;   /* even, 2..16                                                  */
+    int32_t nt;            /* time samples; steps run time = 1 .. nt-2                     */
+    double dt;             /* time step (ms)                                               */
+    int32_t dtype;         /* MIFWI_F32 or MIFWI_F64: element type of every array argument */
+    int32_t nsrc;          /* point sources per shot                                       */
+    int32_t nrec;          /* receivers per shot                                           */
+    int32_t max_shots;     /* shots propagated side by side in one call (batch capacity)   */
+    int32_t device;        /* HIP device ordinal, or -1 for the current device             */
+    int32_t flags;         /* MIFWI_FLAG_*                                                 */
+} mifwi_config;
+
+/* Timing/traffic summary of the last propagation call; stands in for Devito's
+ * PerformanceSummary returned by Operator.apply (seismic/acoustic/wavesolver.py:112-114). */
+typedef struct mifwi_stats {
+    double kernel_ms;       /* GPU time of the last time loop (HIP events on the plan's stream) */
+    double points;          /* grid-point updates performed                                   */
+    double gpointss;        /* points / kernel time / 1e9                                     */
+    double algorithmic_bytes; /* points * bytes-per-update of that operator (20 or 32)       */
+    int32_t launches;       /* kernel launches in that time loop                              */
+    int32_t kernel_kind;    /* 0 generic, 1 tiled 2-D, 2 2.5-D 3-D                            */
+    int64_t device_bytes;   /* device memory currently held by the plan                       */
+} mifwi_stats;
+
+int mifwi_version(void);
+const char *mifwi_last_error(void);
+
+/* Replaces: AcousticWaveSolver.__init__ + the (memoised) Operator construction,
+ * seismic/acoustic/wavesolver.py:28-74. */
+int mifwi_plan_create(const mifwi_config *cfg, mifwi_plan **out);
+int mifwi_plan_destroy(mifwi_plan *plan);
+
+/* Use an existing hipStream_t (e.g. the caller's framework stream) for all work of the plan. */
+int mifwi_set_stream(mifwi_plan *plan, void *hip_stream);
+int mifwi_synchronize(mifwi_plan *plan);
+
+/* Replaces: the `vp` and `damp` arguments of every Operator.apply
+ * (seismic/acoustic/wavesolver.py:109,112; seismic/model.py:13-51,395-400).  vp in km/s and
+ * damp are padded-grid arrays; m = 1/vp^2 is formed on the device. */
+int mifwi_set_model(mifwi_plan *plan, const void *vp, const void *damp);
+
+/* Replaces: the src_coords / rec_coords arguments (SparseTimeFunction.coordinates,
+ * seismic/utils.py:147-186).  src_coords is (nshots, nsrc, ndim).  rec_coords is
+ * (nrec, ndim) shared by all shots when rec_per_shot == 0, else (nshots, nrec, ndim).
+ * Physical coordinates in the units of `spacing`, element type = plan dtype. */
+int mifwi_set_geometry(mifwi_plan *plan, int32_t nshots, const void *src_coords,
+                       const void *rec_coords, int32_t rec_per_shot);
+
+/* Replaces: AcousticWaveSolver.forward -> op_fwd(save).apply(src, rec, u, vp, dt)
+ * (seismic/acoustic/wavesolver.py:76-114; seismic/acoustic/operators.py:98-140).
+ * wavelet: (nt, nsrc) shared by all shots when wavelet_per_shot == 0, else (nshots, nt, nsrc).
+ * rec_out: (nshots, nt, nrec) or NULL.  save != 0 keeps every time level on the device for
+ * mifwi_gradient / mifwi_read_wavefield. */
+int mifwi_forward(mifwi_plan *plan, int32_t nshots, const void *wavelet, int32_t wavelet_per_shot,
+                  void *rec_out, int32_t save);
+
+/* Replaces: AcousticWaveSolver.adjoint -> op_adj().apply(srca, rec, v, vp, dt)
+ * (seismic/acoustic/wavesolver.py:116-151; seismic/acoustic/operators.py:143-180).
+ * rec_in (nshots, nt, nrec); srca_out (nshots, nt, nsrc). */
+int mifwi_adjoint(mifwi_plan *plan, int32_t nshots, const void *rec_in, void *srca_out);
+
+/* Replaces: AcousticWaveSolver.jacobian_adjoint (= gradient) -> op_grad().apply(rec, grad, v, u, vp, dt)
+ * (seismic/acoustic/wavesolver.py:153-205; seismic/acoustic/operators.py:183-225), using the
+ * wavefield saved by the preceding mifwi_forward(save=1) (or mifwi_write_wavefield).
+ * residual (nshots, nt, nrec).  grad (nshots, grid): per-shot gradients on the padded grid;
+ * with accumulate != 0 the result is ADDED to the caller's array (Devito's `Inc`), else stored.
+ * illum: NULL or (nshots, grid), receives sum_t u^2 (fwi.py:170 of the reference). */
+int mifwi_gradient(mifwi_plan *plan, int32_t nshots, const void *residual, void *grad,
+                   int32_t accumulate, void *illum);
+
+/* Fused per-shot objective of fwi.py:131-173 with the L2 misfit (misfit/misfit.py:5-9):
+ * forward(save) -> residual = syn - obs -> fval = 0.5*||residual||^2 -> gradient, all on the
+ * device.  obs (nshots, nt, nrec); fval (nshots) doubles; grad/illum as in mifwi_gradient
+ * (stored, not accumulated; either may be NULL, grad == NULL skips the backward pass);
+ * residual_out / syn_out NULL or (nshots, nt, nrec). */
+int mifwi_l2_misfit_gradient(mifwi_plan *plan, int32_t nshots, const void *wavelet,
+                             int32_t wavelet_per_shot, const void *obs, double *fval, void *grad,
+                             void *illum, void *residual_out, void *syn_out);
+
+/* Access to wavefield time levels of one shot, `u.data[first:first+count]` in the reference
+ * (TimeFunction(save=nt), seismic/acoustic/wavesolver.py:104-106).  which = 0: saved forward
+ * field (level index = time).  which = 1: the three rotating buffers of the last non-saving
+ * forward run, which = 2: those of the last adjoint/gradient run (level index = time % 3). */
+int mifwi_read_wavefield(mifwi_plan *plan, int32_t which, int32_t shot, int32_t first, int32_t count,
+                         void *out);
+int mifwi_write_wavefield(mifwi_plan *plan, int32_t shot, int32_t first, int32_t count, const void *in);
+
+int mifwi_get_stats(mifwi_plan *plan, mifwi_stats *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MIFWI_H */

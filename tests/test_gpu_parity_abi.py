@@ -1,0 +1,103 @@
+"""
+GPU parity of the C-ABI entry points against the CPU oracle on small seeded problems.
+
+Tolerances (float32; the reference states none for its generated code, whose summation order
+is Devito-internal): rel-L2 <= 1e-5 on shot records and wavefields, <= 1e-4 on gradients and
+illumination; float64: 1e-11 / 1e-10.
+"""
+import numpy as np
+import pytest
+
+from helpers import Case, rel_l2
+
+pytestmark = pytest.mark.gpu
+
+TOL = {np.dtype(np.float32): (1e-5, 1e-4), np.dtype(np.float64): (1e-11, 1e-10)}
+
+
+@pytest.fixture(scope="module")
+def mifwi():
+    import mifwi as m
+    return m
+
+
+def _check_case(mifwi, case, flags=0):
+    tol_d, tol_g = TOL[case.dtype]
+    plan = case.plan(mifwi, flags=flags)
+    # forward without saving
+    rec = plan.forward(case.wavelet)
+    refs = [case.oracle_forward(s, save=True) for s in range(case.nshots)]
+    for s in range(case.nshots):
+        assert np.abs(refs[s][0]).max() > 0
+        assert rel_l2(rec[s], refs[s][0]) <= tol_d, ("rec", s)
+    # forward with saving: same records, wavefield matches
+    rec2 = plan.forward(case.wavelet, save=True)
+    assert np.array_equal(rec, rec2)
+    for s in range(case.nshots):
+        u = plan.read_wavefield(0, shot=s)
+        assert u.shape == refs[s][1].shape
+        assert rel_l2(u, refs[s][1]) <= tol_d, ("u", s)
+        assert np.all(u[:2] == 0)
+    # adjoint of the records
+    srca = plan.adjoint(rec)
+    for s in range(case.nshots):
+        ref = case.oracle_adjoint(s, refs[s][0])
+        assert rel_l2(srca[s], ref) <= tol_g, ("srca", s)
+    # gradient of a residual (use the record itself as residual), with illumination
+    grad, illum = plan.gradient(rec, want_illum=True)
+    for s in range(case.nshots):
+        g_ref = case.oracle_gradient(refs[s][0], refs[s][1])
+        assert rel_l2(grad[s], g_ref) <= tol_g, ("grad", s)
+        il_ref = (refs[s][1] * refs[s][1]).sum(axis=0)
+        assert rel_l2(illum[s], il_ref) <= tol_g, ("illum", s)
+    # accumulate semantics (Devito Inc): adding twice doubles
+    g2 = np.array(grad)
+    plan.gradient(rec, grad=g2, accumulate=True)
+    assert rel_l2(g2, 2 * grad) <= 1e-6
+    st = plan.stats()
+    assert st["points"] == (case.nt - 2) * plan.ngrid * case.nshots
+    plan.close()
+
+
+@pytest.mark.parametrize("so", [2, 4, 8, 16])
+def test_2d_orders(mifwi, so):
+    _check_case(mifwi, Case((45, 38), (10.0, 12.5), nbl=9, space_order=so, nt=140, nshots=2, nrec=13))
+
+
+@pytest.mark.parametrize("so", [6, 10, 12, 14])
+def test_2d_other_orders(mifwi, so):
+    _check_case(mifwi, Case((31, 29), (10.0, 10.0), nbl=8, space_order=so, nt=90, nshots=1, nrec=7, seed=3))
+
+
+@pytest.mark.parametrize("so", [4, 8, 16])
+def test_3d_orders(mifwi, so):
+    _check_case(mifwi, Case((14, 12, 13), (10.0, 10.0, 10.0), nbl=6, space_order=so, nt=70, nshots=2, nrec=9, seed=5))
+
+
+def test_1d(mifwi):
+    _check_case(mifwi, Case((101,), (10.0,), nbl=20, space_order=4, nt=200, nshots=2, nrec=5, seed=7))
+
+
+def test_2d_f64(mifwi):
+    _check_case(mifwi, Case((33, 30), (10.0, 10.0), nbl=8, space_order=8, nt=100, nshots=2, nrec=9,
+                            dtype=np.float64, seed=9))
+
+
+def test_multi_source_per_shot(mifwi):
+    _check_case(mifwi, Case((40, 36), (10.0, 10.0), nbl=8, space_order=4, nt=110, nshots=2, nrec=9, nsrc=3, seed=11))
+
+
+def test_error_paths(mifwi):
+    case = Case((20, 20), (10.0, 10.0), nbl=4, space_order=4, nt=20, nshots=1, nrec=3)
+    with pytest.raises(mifwi.MifwiError):
+        mifwi.Plan((20, 20), (10., 10.), (0., 0.), 5, 20, 1.0, 1, 3)       # odd order
+    with pytest.raises(mifwi.MifwiError):
+        mifwi.Plan((20, 20), (10., 10.), (0., 0.), 18, 20, 1.0, 1, 3)      # order too high
+    plan = mifwi.Plan(case.prob.shape_pad, case.prob.spacing, case.prob.origin_pad, 4, case.nt, case.dt, 1, 3)
+    with pytest.raises(mifwi.MifwiError):
+        plan.forward(case.wavelet, nshots=1)                               # no model yet
+    plan.set_model(case.prob.vp, case.prob.damp)
+    plan.set_geometry(case.src, case.rec)
+    with pytest.raises(mifwi.MifwiError):
+        plan.gradient(np.zeros((1, case.nt, 3), np.float32))               # no saved wavefield
+    plan.close()
