@@ -1,0 +1,149 @@
+"""
+`AcousticWaveSolver` with the call signatures of the reference's
+seismic/acoustic/wavesolver.py:10-246, executing on an MI355X through libmifwi instead of
+through Devito-generated C.  forward / adjoint / jacobian_adjoint (alias gradient) are
+implemented; jacobian (Born), the OT4 kernel and pyrevolve checkpointing are not part of this
+package yet and raise.
+"""
+import numpy as np
+
+from ..fields import Function, TimeFunction, DeviceTimeFunction, Constant
+from ..source import PointSource
+
+__all__ = ['AcousticWaveSolver', 'PerformanceSummary']
+
+
+class PerformanceSummary(dict):
+    """Timing record of one operator run (stand-in for Devito's PerformanceSummary)."""
+
+    def __init__(self, stats):
+        super(PerformanceSummary, self).__init__(stats)
+        self.timings = {'section0': stats.get('kernel_ms', 0.0) * 1e-3}
+        self.gpointss = stats.get('gpointss', 0.0)
+        self.gflopss = None
+        self.oi = None
+
+
+def _as_vp_array(vp, model):
+    """Velocity argument -> padded-grid array: Function, Constant, scalar or ndarray."""
+    if vp is None:
+        vp = model.vp
+    data = vp.data if hasattr(vp, 'data') else vp
+    if np.ndim(data) == 0:
+        return np.full(model.grid.shape, data, dtype=model.dtype)
+    data = np.asarray(data)
+    if data.shape == model.grid.shape:
+        return data
+    if data.shape == model.shape:
+        return np.pad(data, model.nbl, mode='edge') if model.nbl else data
+    raise ValueError("vp of shape %s does not match the model" % (data.shape,))
+
+
+class AcousticWaveSolver(object):
+    """
+    Parameters as in the reference (wavesolver.py:16-27): model, geometry, kernel ('OT2'),
+    space_order (default 4).  Extra keyword `device` selects the GPU ordinal.
+    """
+
+    def __init__(self, model, geometry, kernel='OT2', space_order=4, **kwargs):
+        self.model = model
+        self.model._initialize_bcs(bcs="damp")
+        self.geometry = geometry
+        assert self.model.grid == geometry.grid
+        if kernel != 'OT2':
+            raise NotImplementedError("only the OT2 (2nd order in time) kernel is implemented")
+        self.space_order = space_order
+        self.kernel = kernel
+        self._device = kwargs.pop('device', -1)
+        self._kwargs = kwargs
+
+    @property
+    def dt(self):
+        return self.model.critical_dt
+
+    # -- plumbing -----------------------------------------------------------------------------
+    def _entry(self, dt, nsrc, nrec, nt):
+        from mifwi import engine
+        m = self.model
+        return engine.get_plan(m.grid.shape, m.spacing, m.grid.origin, self.space_order, nt, dt, nsrc, nrec,
+                               max_shots=1, dtype=m.dtype, device=self._device)
+
+    def _damp_array(self):
+        d = self.model.damp
+        return d.data if hasattr(d, 'data') else np.full(self.model.grid.shape, d, dtype=self.model.dtype)
+
+    def _load(self, entry, vp, src_coords, rec_coords):
+        vp_arr = np.ascontiguousarray(_as_vp_array(vp, self.model), dtype=self.model.dtype)
+        entry.plan.set_model(vp_arr, np.ascontiguousarray(self._damp_array(), dtype=self.model.dtype))
+        entry.plan.set_geometry(src_coords, rec_coords)
+
+    # -- operators ------------------------------------------------------------------------------
+    def forward(self, src=None, rec=None, u=None, vp=None, save=None, **kwargs):
+        """Forward modelling; returns (rec, u, summary) (wavesolver.py:76-114)."""
+        src = src or self.geometry.src
+        rec = rec or self.geometry.rec
+        dt = kwargs.pop('dt', self.dt)
+        nt = src.data.shape[0]
+        entry = self._entry(dt, src.data.shape[1], rec.data.shape[1], nt)
+        self._load(entry, vp, src.coordinates.data, rec.coordinates.data)
+        which = 0 if save else 1
+        out_u = u
+        if u is None:
+            out_u = DeviceTimeFunction('u', self.model.grid, nt if save else None, entry, None, which,
+                                       time_order=2, space_order=self.space_order)
+        token = entry.claim(which, out_u if u is None else None)
+        data = entry.plan.forward(src.data, nshots=1, save=bool(save))
+        rec.data[:] = data[0]
+        if u is None:
+            out_u._token = token
+        else:
+            u.data[...] = entry.plan.read_wavefield(which, shot=0)
+        return rec, out_u, PerformanceSummary(entry.plan.stats())
+
+    def adjoint(self, rec, srca=None, v=None, vp=None, **kwargs):
+        """Adjoint modelling; returns (srca, v, summary) (wavesolver.py:116-151)."""
+        srca = srca or self.geometry.new_src(name='srca', src_type=None)
+        dt = kwargs.pop('dt', self.dt)
+        nt = rec.data.shape[0]
+        entry = self._entry(dt, srca.data.shape[1], rec.data.shape[1], nt)
+        self._load(entry, vp, srca.coordinates.data, rec.coordinates.data)
+        out_v = v
+        if v is None:
+            out_v = DeviceTimeFunction('v', self.model.grid, None, entry, None, 2, time_order=2,
+                                       space_order=self.space_order)
+        token = entry.claim(2, out_v if v is None else None)
+        srca.data[:] = entry.plan.adjoint(rec.data[None], nshots=1)[0]
+        if v is None:
+            out_v._token = token
+        else:
+            v.data[...] = entry.plan.read_wavefield(2, shot=0)
+        return srca, out_v, PerformanceSummary(entry.plan.stats())
+
+    def jacobian_adjoint(self, rec, u, v=None, grad=None, vp=None, checkpointing=False, **kwargs):
+        """Adjoint Jacobian (FWI gradient); accumulates into `grad` and returns (grad, summary)
+        (wavesolver.py:153-205)."""
+        if checkpointing:
+            raise NotImplementedError("pyrevolve checkpointing is not available; the saved wavefield stays on the GPU")
+        dt = kwargs.pop('dt', self.dt)
+        grad = grad or Function(name='grad', grid=self.model.grid)
+        nt = rec.data.shape[0]
+        entry = self._entry(dt, self.geometry.nsrc, rec.data.shape[1], nt)
+        self._load(entry, vp, self.geometry.src_positions, rec.coordinates.data)
+        if not (isinstance(u, DeviceTimeFunction) and u._entry is entry and u.on_device()):
+            ud = np.ascontiguousarray(u.data, dtype=self.model.dtype)
+            assert ud.shape[0] == nt, "u must hold every time level (created with save=True)"
+            entry.claim(0)
+            entry.plan.write_wavefield(ud, shot=0)
+        entry.claim(2)
+        entry.plan.gradient(rec.data[None], nshots=1, grad=grad.data.reshape((1,) + grad.data.shape),
+                            accumulate=True)
+        if v is not None:
+            v.data[...] = entry.plan.read_wavefield(2, shot=0)
+        return grad, PerformanceSummary(entry.plan.stats())
+
+    def jacobian(self, dmin, src=None, rec=None, u=None, U=None, vp=None, **kwargs):
+        raise NotImplementedError("Born modelling (wavesolver.py:207-242 of the reference) is not implemented yet")
+
+    # Backward compatibility
+    born = jacobian
+    gradient = jacobian_adjoint

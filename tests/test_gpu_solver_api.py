@@ -1,0 +1,165 @@
+"""
+The reference's own known-answer tests, run through the drop-in Python interface on the GPU.
+The bodies deliberately read like the reference's scripts:
+  * seismic/inversion/fwi.py:13-121       (circle model FWI: 39113 / -821 / 2442 / 3828, atol 10)
+  * seismic/acoustic/acoustic_example.py:26-40,75-79   (3-D layered forward: ||rec|| = 459.1678, rtol 1e-3, f64)
+plus fwi.py-level parity of fwi_obj_multi / fwi_loss against the oracle's restatement.
+"""
+import numpy as np
+import pytest
+
+from helpers import rel_l2
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def test_kat_circle_fwi_through_solver_api():
+    from seismic import demo_model, AcquisitionGeometry, Receiver, Function
+    from seismic.acoustic import AcousticWaveSolver
+
+    nshots, nreceivers, fwi_iterations = 9, 101, 5
+    shape, spacing, origin = (101, 101), (10., 10.), (0., 0.)
+    model = demo_model('circle-isotropic', vp_circle=3.0, vp_background=2.5, origin=origin, shape=shape,
+                       spacing=spacing, nbl=40)
+    model0 = demo_model('circle-isotropic', vp_circle=2.5, vp_background=2.5, origin=origin, shape=shape,
+                        spacing=spacing, nbl=40, grid=model.grid)
+    assert model.grid == model0.grid
+    t0, tn, f0 = 0., 1000., 0.010
+    src_coordinates = np.empty((1, 2))
+    src_coordinates[0, :] = np.array(model.domain_size) * .5
+    src_coordinates[0, 0] = 20.
+    rec_coordinates = np.empty((nreceivers, 2))
+    rec_coordinates[:, 1] = np.linspace(0, model.domain_size[0], num=nreceivers)
+    rec_coordinates[:, 0] = 980.
+    geometry = AcquisitionGeometry(model, rec_coordinates, src_coordinates, t0, tn, f0=f0, src_type='Ricker')
+    solver = AcousticWaveSolver(model, geometry, space_order=4)
+    source_locations = np.empty((nshots, 2), dtype=np.float32)
+    source_locations[:, 0] = 20.
+    source_locations[:, 1] = np.linspace(0., 1000, num=nshots)
+
+    def fwi_gradient(vp_in):
+        grad = Function(name="grad", grid=model.grid)
+        objective = 0.
+        for i in range(nshots):
+            residual = Receiver(name='residual', grid=model.grid, time_range=geometry.time_axis,
+                                coordinates=geometry.rec_positions)
+            d_obs = Receiver(name='d_obs', grid=model.grid, time_range=geometry.time_axis,
+                             coordinates=geometry.rec_positions)
+            d_syn = Receiver(name='d_syn', grid=model.grid, time_range=geometry.time_axis,
+                             coordinates=geometry.rec_positions)
+            solver.geometry.src_positions[0, :] = source_locations[i, :]
+            solver.forward(vp=model.vp, rec=d_obs)
+            _, u0, _ = solver.forward(vp=vp_in, save=True, rec=d_syn)
+            residual.data[:] = d_syn.data[:] - d_obs.data[:]
+            objective += .5 * np.linalg.norm(residual.data.ravel().astype(np.float64)) ** 2
+            solver.jacobian_adjoint(rec=residual, u=u0, vp=vp_in, grad=grad)
+        return objective, grad
+
+    ff, update = fwi_gradient(model0.vp)
+    print(ff, update.data.min(), update.data.max())
+    assert np.isclose(ff, 39113, atol=1e1, rtol=0)
+    assert np.isclose(update.data.min(), -821, atol=1e1, rtol=0)
+    assert np.isclose(update.data.max(), 2442, atol=1e1, rtol=0)
+
+    history = np.zeros((fwi_iterations, 1))
+    for i in range(0, fwi_iterations):
+        phi, direction = fwi_gradient(model0.vp)
+        history[i] = phi
+        alpha = .05 / direction.data.max()
+        # update_with_box of seismic/inversion/inversion_utils.py:28-39
+        model0.vp.data[...] = np.clip(model0.vp.data + alpha * direction.data, 2.0, 3.5)
+    print(history.ravel())
+    assert np.isclose(history[-1], 3828, atol=1e1, rtol=0)
+
+
+def test_kat_layers3d_forward_f64_through_solver_api():
+    from seismic import demo_model, setup_geometry
+    from seismic.acoustic import AcousticWaveSolver
+    model = demo_model('layers-isotropic', space_order=4, shape=(50, 50, 50), nbl=40, dtype=np.float64,
+                       spacing=(20.0, 20.0, 20.0))
+    geometry = setup_geometry(model, 1000.0)
+    solver = AcousticWaveSolver(model, geometry, kernel='OT2', space_order=4)
+    rec, u, summary = solver.forward(save=False)
+    nrm = np.linalg.norm(rec.data.ravel())
+    print("||rec|| =", nrm, summary)
+    assert np.isclose(nrm, 459.1678, rtol=1e-3, atol=0)
+    assert u.data.shape == (3, 130, 130, 130)
+
+
+def _marmousi_like(nshots=3, so=8):
+    """A cut of the Marmousi raster, small enough for the oracle, with the acquisition pattern of
+    marmousi_fwi.py:62-117 (sources and receivers at 2 cells depth, bathymetry mask)."""
+    import os
+    from seismic import Model, AcquisitionGeometry
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "model_data", "SMARMN")
+    full_t = np.fromfile(os.path.join(root, "vp.true"), dtype=np.float32).reshape(300, 106) / 1000
+    full_s = np.fromfile(os.path.join(root, "vp.smooth_20"), dtype=np.float32).reshape(300, 106) / 1000
+    shape = (90, 60)
+    true_vp, smooth_vp = full_t[100:190, :60].copy(), full_s[100:190, :60].copy()
+    spacing, nbl, dt = (30., 30.), 20, 2.95
+    kw = dict(origin=(0, 0), spacing=spacing, shape=shape, space_order=so, nbl=nbl, fs=False, dt=dt)
+    true_model = Model(vp=true_vp, **kw)
+    init_model = Model(vp=smooth_vp, **kw)
+    src = np.empty((nshots, 2))
+    src[:, 0] = np.linspace(0, true_model.domain_size[0], num=nshots)
+    src[:, -1] = 2 * spacing[0]
+    rec = np.empty((shape[0], 2))
+    rec[:, 0] = np.linspace(spacing[0], true_model.domain_size[0] - spacing[0], num=shape[0])
+    rec[:, 1] = 2 * spacing[0]
+    g1 = AcquisitionGeometry(true_model, rec, src, 0., 900., f0=0.007, src_type='Ricker')
+    g0 = AcquisitionGeometry(init_model, rec, src, 0., 900., f0=0.007, src_type='Ricker')
+    mask = np.ones(shape, dtype=np.float32)
+    mask[:, :7] = 0
+    return dict(true_vp=true_vp, smooth_vp=smooth_vp, g1=g1, g0=g0, mask=mask, spacing=spacing, nbl=nbl, dt=dt,
+                so=so, src=src, rec=rec)
+
+
+@pytest.mark.parametrize("with_direct", [False, True])
+def test_fwi_loss_matches_oracle(with_direct):
+    from fwi import fm_multi, fwi_loss, fwi_obj_multi
+    from misfit import least_square
+    from seismic import Model, AcquisitionGeometry
+    c = _marmousi_like()
+    obs = fm_multi(c["g1"], save=False)
+    # oracle: same observed data, objective and gradient
+    p_true = orc.Problem(c["true_vp"], c["spacing"], c["nbl"], c["so"], dt=c["dt"])
+    p_init = orc.Problem(c["smooth_vp"], c["spacing"], c["nbl"], c["so"], dt=c["dt"])
+    wavelet = c["g1"].src.data[:, :1]
+    obs_ref = [p_true.forward(c["src"][i], wavelet, c["rec"], dt=c["dt"])[0] for i in range(len(c["src"]))]
+    for i in range(len(obs_ref)):
+        assert rel_l2(obs[i].data, obs_ref[i]) < 1e-5
+    direct = None
+    if with_direct:
+        cm = Model(vp=np.ones(c["true_vp"].shape) * 1.5, origin=(0, 0), spacing=c["spacing"],
+                   shape=c["true_vp"].shape, space_order=c["so"], nbl=c["nbl"], fs=False, dt=c["dt"])
+        direct = fm_multi(AcquisitionGeometry(cm, c["rec"], c["src"], 0., 900., f0=0.007, src_type='Ricker'))
+    m0 = 1. / (c["smooth_vp"].reshape(-1).astype(np.float64)) ** 2
+    fval, grad, res = fwi_loss(m0, c["g0"], obs, least_square, direct, c["mask"], True)
+    f_ref, g_ref, r_ref = orc.fwi_obj_multi(p_init, c["src"], c["rec"], wavelet, obs_ref, dt=c["dt"],
+                                            mask=c["mask"], precond=True)
+    print(fval, f_ref, rel_l2(grad, g_ref))
+    assert abs(fval - f_ref) <= 2e-5 * abs(f_ref)
+    assert grad.dtype == np.float64 and grad.shape == g_ref.shape
+    assert rel_l2(grad, g_ref) < 2e-4
+    for i in range(len(res)):
+        assert rel_l2(res[i], r_ref[i]) < 2e-4
+    # forward-only evaluation (line-search trial, minimize.py:67 of the reference)
+    f2, g2, _ = fwi_obj_multi(c["g0"], obs, least_square, direct, c["mask"], True, calc_grad=False)
+    assert abs(f2 - fval) <= 1e-6 * abs(fval)
+    assert not g2.any()
+
+
+def test_fwi_obj_single_matches_batched():
+    from fwi import fm_multi, fwi_obj_multi, fwi_obj_single, _shot_geometry
+    from misfit import least_square
+    c = _marmousi_like(nshots=2, so=4)
+    obs = fm_multi(c["g1"])
+    f_b, g_b, _ = fwi_obj_multi(c["g0"], obs, least_square, None, None, False, True)
+    f_s, g_s = 0., np.zeros(c["true_vp"].shape)
+    for i in range(2):
+        f_, g_, r_, il_ = fwi_obj_single(_shot_geometry(c["g0"], i), obs[i], least_square, None, None, True)
+        f_s += f_
+        g_s += g_
+    assert abs(f_b - f_s) <= 1e-5 * abs(f_s)
+    assert rel_l2(g_b, g_s.ravel()) < 1e-5

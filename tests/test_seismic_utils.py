@@ -1,0 +1,121 @@
+"""
+Host-side data model tests, modelled on the reference's seismic/test_seismic_utils.py:17-97
+(damp centre value and re-initialisation, user dt, default geometry, resampling, naming) plus
+checks of the numpy mirror against the oracle's restatement of the same formulas.
+"""
+import numpy as np
+import pytest
+
+from seismic import Model, setup_geometry, AcquisitionGeometry, demo_model, TimeAxis, RickerSource
+from oracle import oracle as orc
+
+
+def not_bcs(bc):
+    return ("mask", 1) if bc == "damp" else ("damp", 0)
+
+
+@pytest.mark.parametrize('nbl, bcs', [(20, ("mask", 1)), (0, ("mask", 1)), (20, ("damp", 0)), (0, ("damp", 0))])
+def test_damp(nbl, bcs):
+    shape = (21, 21)
+    vp = np.ones(shape)
+    model = Model((0, 0), (10, 10), shape, 4, vp, nbl=nbl, bcs=bcs[0])
+    try:
+        center = model.damp.data[tuple(s // 2 for s in model.damp.shape)]
+    except AttributeError:
+        center = model.damp
+    assert all([s == s0 + 2 * nbl for s, s0 in zip(model.vp.shape, shape)])
+    assert center == bcs[1]
+    switch_bcs = not_bcs(bcs[0])
+    model._initialize_bcs(bcs=switch_bcs[0])
+    try:
+        center = model.damp.data[tuple(s // 2 for s in model.damp.shape)]
+    except AttributeError:
+        center = model.damp
+    assert center == switch_bcs[1]
+
+
+@pytest.mark.parametrize('shape', [(41,), (21, 21), (11, 11, 11)])
+def test_default_geom(shape):
+    vp = np.ones(shape)
+    o = tuple([0] * len(shape))
+    d = tuple([10] * len(shape))
+    model = Model(o, d, shape, 4, vp, nbl=20, dt=1)
+    assert model.critical_dt == 1
+    geometry = setup_geometry(model, 250)
+    nrec = shape[0] * (shape[1] if len(shape) > 2 else 1)
+    assert geometry.grid == model.grid
+    assert geometry.nrec == nrec
+    assert geometry.nsrc == 1
+    assert geometry.src_type == "Ricker"
+    assert geometry.rec.shape == (251, nrec)
+    assert np.linalg.norm(geometry.rec.data) == 0
+    assert geometry.src.shape == (251, 1)
+    assert np.linalg.norm(geometry.new_src(src_type=None).data) == 0
+    rec2 = geometry.rec.resample(num=501)
+    assert rec2.shape == (501, nrec)
+    assert rec2.grid == model.grid
+    assert geometry.new_rec(name="bonjour").name == "bonjour"
+    assert geometry.new_src(name="bonjour").name == "bonjour"
+
+
+@pytest.mark.parametrize('shape', [(41,), (21, 21), (11, 11, 11)])
+def test_geom(shape):
+    vp = np.ones(shape)
+    o = tuple([0] * len(shape))
+    d = tuple([10] * len(shape))
+    model = Model(o, d, shape, 4, vp, nbl=20, dt=1)
+    nrec, nsrc = 31, 4
+    geometry = AcquisitionGeometry(model, np.ones((nrec, len(shape))), np.ones((nsrc, len(shape))), t0=0.0, tn=250)
+    assert geometry.nrec == nrec and geometry.nsrc == nsrc and geometry.src_type is None
+    assert geometry.rec.shape == (251, nrec)
+    assert geometry.src.shape == (251, nsrc)
+    assert np.linalg.norm(geometry.src.data) == 0
+    assert geometry.rec.resample(num=501).shape == (501, nrec)
+
+
+def test_user_dt_above_cfl_raises():
+    model = Model((0, 0), (10, 10), (21, 21), 4, np.full((21, 21), 3.0), nbl=5, dt=50.0)
+    with pytest.raises(ValueError):
+        model.critical_dt
+
+
+@pytest.mark.parametrize('so, ndim', [(2, 2), (4, 2), (8, 2), (16, 2), (4, 3), (8, 3)])
+def test_model_matches_oracle_formulas(so, ndim):
+    shape = (23, 19, 17)[:ndim]
+    spacing = (10.0, 12.5, 7.5)[:ndim]
+    rng = np.random.default_rng(so)
+    vp = (1.5 + 2 * rng.random(shape)).astype(np.float32)
+    model = Model((0.,) * ndim, spacing, shape, so, vp, nbl=7, bcs="damp")
+    prob = orc.Problem(vp, spacing, 7, so)
+    assert model.critical_dt == prob.critical_dt
+    np.testing.assert_array_equal(model.vp.data, prob.vp)
+    np.testing.assert_allclose(model.damp.data, prob.damp, rtol=2e-6, atol=0)
+    assert tuple(float(o) for o in model.grid.origin) == prob.origin_pad
+
+
+def test_time_axis_and_ricker_match_oracle():
+    ta = TimeAxis(start=0.0, stop=1000.0, step=2.041)
+    nt, tv = orc.time_axis(0.0, 1000.0, 2.041)
+    assert ta.num == nt == 491
+    np.testing.assert_array_equal(ta.time_values, tv)
+    model = demo_model('constant-isotropic', space_order=4)
+    assert model.critical_dt == np.float32(3.698)
+    geom = setup_geometry(model, 1000.)
+    src = geom.src
+    assert isinstance(src, RickerSource)
+    ref = orc.ricker(0.010, src.time_values).astype(np.float32)
+    np.testing.assert_array_equal(src.data[:, 0], ref)
+    with pytest.raises(ValueError):
+        TimeAxis(start=0, stop=1, step=0.1, num=11)
+
+
+def test_update_repads_and_m():
+    model = demo_model('circle-isotropic', nbl=6, shape=(31, 31))
+    new = np.full((31, 31), 2.0, dtype=np.float64)
+    new[0, :] = 3.0
+    model.update('vp', new)
+    assert model.vp.data.dtype == np.float32
+    assert np.all(model.vp.data[:7, :] == 3.0) and np.all(model.vp.data[7:, :] == 2.0)
+    np.testing.assert_allclose(model.m, 1 / model.vp.data ** 2)
+    with pytest.raises(ValueError):
+        model.update('vp', np.ones((5, 5)))
