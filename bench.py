@@ -1,0 +1,231 @@
+#!/usr/bin/env python
+"""
+Benchmark of the acoustic FWI hot path on MI355X.
+
+Metric (BASELINE.json): Gpoints/s (forward + adjoint/gradient) on Marmousi-II, 8 shots per GPU.
+One "step" = one gradient evaluation of the L2 objective for this rank's 8 shots:
+forward modelling with the wavefield saved on the device, residual against the observed data,
+backward propagation with zero-lag cross-correlation, per-shot source/receiver muting and the
+sum over shots; with N > 1 ranks the summed gradient, illumination and objective are
+all-reduced over RCCL.  Each rank owns 8 different shots of an 8N-shot survey (weak scaling).
+
+    python bench.py --gpus 1 --steps 5 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Rank 0 prints ONE JSON line.  `roofline` describes the dominant kernel (the gradient time step);
+`cpu_baseline` is the CPU oracle (a restatement of the Devito CPU path, not Devito itself) timed
+on the host cores for a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, "devito-fwi_amd")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak
+SHOTS_PER_GPU = 8
+
+
+def marmousi2(space_order):
+    """Marmousi-II set-up of the reference's marmousi2_fwi.py:61-103 (rasters are the reference's
+    model_data/SMARM2 files, kept as fixtures)."""
+    from seismic import Model
+    d = os.path.join(ROOT, "tests", "golden", "model_data", "SMARM2")
+    shape = (340, 140)
+    true_vp = np.fromfile(os.path.join(d, "vp.true"), dtype=np.float32).reshape(shape) / 1000
+    smooth_vp = np.fromfile(os.path.join(d, "vp.smooth_20"), dtype=np.float32).reshape(shape) / 1000
+    kw = dict(origin=(0, 0), spacing=(30., 30.), shape=shape, space_order=space_order, nbl=40, fs=False, dt=3.0,
+              bcs="damp")
+    return Model(vp=true_vp, **kw), Model(vp=smooth_vp, **kw)
+
+
+def acquisition(model, nshots_total):
+    spacing = model.spacing
+    src = np.empty((nshots_total, 2))
+    src[:, 0] = np.linspace(0, model.domain_size[0], num=nshots_total)
+    src[:, -1] = 2 * spacing[0]
+    nrec = model.shape[0]
+    rec = np.empty((nrec, 2))
+    rec[:, 0] = np.linspace(spacing[0], model.domain_size[0] - spacing[0], num=nrec)
+    rec[:, 1] = 2 * spacing[0]
+    return src, rec
+
+
+def cpu_baseline(true_model, init_model, src, rec, wavelet, dt, space_order, nshots=2):
+    """Oracle (CPU restatement of the Devito path) on `nshots` shots of the same workload."""
+    from oracle import oracle as orc
+    nthreads = int(os.environ.get("OMP_NUM_THREADS", "0")) or (os.cpu_count() or 1)
+    nbl = true_model.nbl
+    p_true = orc.Problem(true_model.vp.data[nbl:-nbl, nbl:-nbl], true_model.spacing, nbl, space_order, dt=dt)
+    p_init = orc.Problem(init_model.vp.data[nbl:-nbl, nbl:-nbl], true_model.spacing, nbl, space_order, dt=dt)
+    obs = [p_true.forward(src[i], wavelet, rec, dt=dt)[0] for i in range(nshots)]
+    t0 = time.perf_counter()
+    pts = 0
+    for i in range(nshots):
+        syn, u = p_init.forward(src[i], wavelet, rec, dt=dt, save=True)
+        p_init.gradient(rec, syn - obs[i], u, dt=dt)
+        pts += 2 * (wavelet.shape[0] - 2) * int(np.prod(p_init.shape_pad))
+    el = time.perf_counter() - t0
+    return {"value": pts / el / 1e9, "unit": "Gpoints/s", "cores": nthreads, "kind": "port",
+            "sample": "%d shots of the same Marmousi-II workload (forward with saved wavefield + gradient, "
+                      "full nt=%d), shots serial, OpenMP over the grid; %.1f s" % (nshots, wavelet.shape[0], el)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--space-order", type=int, default=16)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--flags", type=int, default=0, help="MIFWI_FLAG_* bits for the plan (debugging)")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import mifwi
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run" % (args.gpus, world))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    so = args.space_order
+    true_model, init_model = marmousi2(so)
+    nshots_total = SHOTS_PER_GPU * world
+    src_all, rec = acquisition(true_model, nshots_total)
+    mine = list(range(rank * SHOTS_PER_GPU, (rank + 1) * SHOTS_PER_GPU))
+    src = src_all[mine]
+
+    from seismic import AcquisitionGeometry
+    geom = AcquisitionGeometry(true_model, rec, src[0], 0., 4500., f0=0.007, src_type='Ricker')
+    nt, dt = geom.nt, float(true_model.critical_dt)
+    wavelet = np.ascontiguousarray(geom.src.data)                       # (nt, 1) float32
+    shape_pad = true_model.grid.shape
+    ngrid = int(np.prod(shape_pad))
+    nbl = true_model.nbl
+
+    plan = mifwi.Plan(shape_pad, true_model.spacing, true_model.grid.origin, so, nt, dt, 1, rec.shape[0],
+                      max_shots=SHOTS_PER_GPU, dtype=np.float32, device=local_rank, flags=args.flags)
+    plan.set_geometry(src.reshape(SHOTS_PER_GPU, 1, 2), rec)
+
+    # everything the timed region reads is resident in HBM before it starts
+    d_vp_true = torch.from_numpy(np.ascontiguousarray(true_model.vp.data)).to(dev)
+    d_vp_init = torch.from_numpy(np.ascontiguousarray(init_model.vp.data)).to(dev)
+    d_damp = torch.from_numpy(np.ascontiguousarray(true_model.damp.data)).to(dev)
+    d_wavelet = torch.from_numpy(wavelet).to(dev)
+    d_obs = torch.empty((SHOTS_PER_GPU, nt, rec.shape[0]), dtype=torch.float32, device=dev)
+    plan.set_model(d_vp_true, d_damp)
+    plan.forward(d_wavelet, nshots=SHOTS_PER_GPU, rec_out=d_obs)        # observed data (untimed)
+    plan.set_model(d_vp_init, d_damp)
+
+    from fwi import _mute_factor
+    mute = np.stack([_mute_factor(true_model.shape, true_model.spacing, src[k], rec) for k in range(SHOTS_PER_GPU)])
+    d_mute = torch.from_numpy(mute.astype(np.float32)).to(dev)
+    d_grad = torch.zeros((SHOTS_PER_GPU,) + shape_pad, dtype=torch.float32, device=dev)
+    d_illum = torch.zeros_like(d_grad)
+    d_fval = torch.zeros(SHOTS_PER_GPU, dtype=torch.float64, device=dev)
+    torch.cuda.synchronize()
+
+    fwd_stats, grad_stats = [], []
+
+    def step():
+        plan.l2_misfit_gradient(d_wavelet, d_obs, nshots=SHOTS_PER_GPU, grad=d_grad, illum=d_illum, fval=d_fval,
+                                want_illum=True)
+        st = plan.stats()
+        g = (d_grad[:, nbl:-nbl, nbl:-nbl] * d_mute).sum(0)
+        il = (d_illum[:, nbl:-nbl, nbl:-nbl] * d_mute).sum(0)
+        packed = torch.cat([g.reshape(-1).double(), il.reshape(-1).double(), d_fval.sum().reshape(1)])
+        if world > 1:
+            dist.all_reduce(packed)
+        return packed, st
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        packed, st = step()
+        fwd_stats.append((st["fwd_ms"], st["fwd_launches"]))
+        grad_stats.append((st["bwd_ms"], st["bwd_launches"]))
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    pts_per_step = 2.0 * (nt - 2) * ngrid * SHOTS_PER_GPU * world
+    value = pts_per_step * args.steps / elapsed / 1e9
+    fval = float(packed[-1].item())
+
+    # roofline of the dominant kernel (gradient time step): algorithmic 32 B per point update,
+    # points per launch = padded grid x shots in the launch; duration = HIP-event time of the
+    # backward time loop on the plan's stream / launches of that loop.
+    bwd_ms = float(np.mean([m for m, _ in grad_stats]))
+    bwd_launches = grad_stats[-1][1]
+    fwd_ms = float(np.mean([m for m, _ in fwd_stats]))
+    fwd_launches = fwd_stats[-1][1]
+    steps_per_loop = nt - 2
+    g_bytes_loop = 32.0 * ngrid * SHOTS_PER_GPU * steps_per_loop
+    f_bytes_loop = 20.0 * ngrid * SHOTS_PER_GPU * steps_per_loop
+    g_ach = g_bytes_loop / (bwd_ms * 1e-3) / 1e9
+    f_ach = f_bytes_loop / (fwd_ms * 1e-3) / 1e9
+    roofline = {"bound": "hbm", "achieved": g_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": g_ach / HBM_PEAK_GBS, "traffic": None,
+                "kernel": st["bwd_kernel"], "launches_per_loop": bwd_launches,
+                "avg_launch_us": bwd_ms * 1e3 / max(1, bwd_launches),
+                "bytes_per_launch": g_bytes_loop / max(1, bwd_launches),
+                "timing": "HIP events around the backward time loop on the plan's stream / launches "
+                          "(includes inter-kernel gaps)"}
+    roofline_fwd = {"bound": "hbm", "achieved": f_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": f_ach / HBM_PEAK_GBS, "traffic": None, "kernel": st["fwd_kernel"],
+                    "launches_per_loop": fwd_launches, "avg_launch_us": fwd_ms * 1e3 / max(1, fwd_launches)}
+
+    out = {
+        "metric": "Gpoints/s (fwd+adj), Marmousi-II, 8 shots per GPU",
+        "value": value, "unit": "Gpoints/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32",
+        "data": "Marmousi-II vp rasters of the reference (model_data/SMARM2); observed data synthesised by "
+                "forward modelling the true model; start model = smooth_20",
+        "config": {"workload": "Marmousi-II (SMARM2 340x140, nbl 40 -> 420x220) acoustic, space_order=%d, "
+                               "dt=3.0 ms, nt=%d, %d shots per GPU, L2 misfit gradient (forward with saved "
+                               "wavefield + adjoint/gradient + per-shot muting + shot sum%s)"
+                               % (so, nt, SHOTS_PER_GPU, " + RCCL all-reduce" if world > 1 else ""),
+                   "shots_total": nshots_total, "grid_padded": list(shape_pad), "nt": nt, "space_order": so,
+                   "parallelism": "shots sharded %d per GPU" % SHOTS_PER_GPU},
+        "gradient_eval_ms": elapsed / args.steps * 1e3,
+        "objective": fval,
+        "roofline": roofline, "roofline_forward": roofline_fwd,
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(true_model, init_model, src_all, rec, wavelet, dt, so)
+    if rank == 0:
+        print(json.dumps(out))
+    plan.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -396,8 +396,16 @@ static int check_run(Plan &p, int nshots)
     return MIFWI_OK;
 }
 
-static void fill_stats(Plan &p, double ms, double steps, int nshots, double bytes_per_point, int launches)
+static void fill_stats(Plan &p, double ms, double steps, int nshots, double bytes_per_point, int launches,
+                       bool backward)
 {
+    if (backward) {
+        p.stats.bwd_ms = ms;
+        p.stats.bwd_launches = launches;
+    } else {
+        p.stats.fwd_ms = ms;
+        p.stats.fwd_launches = launches;
+    }
     p.stats.kernel_ms = ms;
     p.stats.points = steps * (double)p.L.ngrid * nshots;
     p.stats.gpointss = ms > 0 ? p.stats.points / (ms * 1e-3) / 1e9 : 0.0;
@@ -473,7 +481,7 @@ static int run_forward(Plan &p, int nshots, int save)
     MIFWI_HIP(hipEventSynchronize(p.ev1));
     float ms = 0;
     MIFWI_HIP(hipEventElapsedTime(&ms, p.ev0, p.ev1));
-    fill_stats(p, ms, nt - 2, nshots, 20.0, launches);
+    fill_stats(p, ms, nt - 2, nshots, 20.0, launches, false);
     if (save) {
         p.saved_valid = true;
         p.saved_shots = nshots;
@@ -549,7 +557,7 @@ static int run_backward(Plan &p, int nshots, bool with_grad, bool with_illum)
     MIFWI_HIP(hipEventSynchronize(p.ev1));
     float ms = 0;
     MIFWI_HIP(hipEventElapsedTime(&ms, p.ev0, p.ev1));
-    fill_stats(p, ms, nt - 2, nshots, with_grad ? 32.0 : 20.0, launches);
+    fill_stats(p, ms, nt - 2, nshots, with_grad ? 32.0 : 20.0, launches, true);
     p.rot_v_valid = true;
     return MIFWI_OK;
 }

@@ -33,8 +33,13 @@ class _Config(ctypes.Structure):
 
 class _Stats(ctypes.Structure):
     _fields_ = [("kernel_ms", ctypes.c_double), ("points", ctypes.c_double), ("gpointss", ctypes.c_double),
-                ("algorithmic_bytes", ctypes.c_double), ("launches", ctypes.c_int32),
+                ("algorithmic_bytes", ctypes.c_double), ("fwd_ms", ctypes.c_double), ("bwd_ms", ctypes.c_double),
+                ("launches", ctypes.c_int32), ("fwd_launches", ctypes.c_int32), ("bwd_launches", ctypes.c_int32),
                 ("kernel_kind", ctypes.c_int32), ("device_bytes", ctypes.c_int64)]
+
+KERNEL_NAMES = {0: ("step_generic_kernel", "step_generic_kernel<GRAD>"),
+                1: ("step2d_kernel", "step2d_kernel<GRAD>"),
+                2: ("step3d_kernel", "step3d_kernel<GRAD>")}
 
 
 _LIB = None
@@ -246,4 +251,6 @@ class Plan(object):
     def stats(self):
         st = _Stats()
         self._check(self._lib.mifwi_get_stats(self._h, ctypes.byref(st)))
-        return {k: getattr(st, k) for k, _ in _Stats._fields_}
+        out = {k: getattr(st, k) for k, _ in _Stats._fields_}
+        out["fwd_kernel"], out["bwd_kernel"] = KERNEL_NAMES.get(st.kernel_kind, ("?", "?"))
+        return out

@@ -85,11 +85,15 @@ typedef struct mifwi_config {
 /* Timing/traffic summary of the last propagation call; stands in for Devito's
  * PerformanceSummary returned by Operator.apply (seismic/acoustic/wavesolver.py:112-114). */
 typedef struct mifwi_stats {
-    double kernel_ms;       /* GPU time of the last time loop (HIP events on the plan's stream) */
+    double kernel_ms;       /* GPU time of the time loops of the last call (HIP events on the plan's stream) */
     double points;          /* grid-point updates performed                                   */
     double gpointss;        /* points / kernel time / 1e9                                     */
     double algorithmic_bytes; /* points * bytes-per-update of that operator (20 or 32)       */
-    int32_t launches;       /* kernel launches in that time loop                              */
+    double fwd_ms;          /* GPU time of the last forward time loop                         */
+    double bwd_ms;          /* GPU time of the last backward (adjoint / gradient) time loop   */
+    int32_t launches;       /* kernel launches of the last call                               */
+    int32_t fwd_launches;   /* kernel launches of the last forward time loop                  */
+    int32_t bwd_launches;   /* kernel launches of the last backward time loop                 */
     int32_t kernel_kind;    /* 0 generic, 1 tiled 2-D, 2 2.5-D 3-D                            */
     int64_t device_bytes;   /* device memory currently held by the plan                       */
 } mifwi_stats;
