@@ -1,0 +1,221 @@
+// Tiled 2-D time-stepping kernel (float32): the fast path for 2-D acquisitions.
+//
+// One launch advances every shot of the batch by one time step and also does that step's sparse
+// work, so a time loop is exactly one kernel per step:
+//   * tile blocks: each 256-thread block owns a TX x TZ tile of one shot.  The tile of the field
+//     read through the stencil (plus a halo of R rows / round_up(R,4) columns) is staged in LDS with
+//     16-byte loads; every thread then produces 4 consecutive z points from ds_read_b128 reads (the
+//     z line once, 2R row neighbours), reads old/m/eta with one aligned 16-byte load each and
+//     stores 16 bytes.  The gradient variant also reads the three saved forward levels and
+//     read-modify-writes grad (and illum).
+//   * after its stores, a tile block adds the injected source/receiver terms for the grid cells it
+//     owns (per-tile CSR built on the host: one thread per cell, fixed summation order, no
+//     atomics).
+//   * extra blocks at the end of the grid interpolate the field being read at the receiver (or
+//     source) positions.
+// Block ids are dealt shot-fastest: with a multiple of 8 shots every block of a shot carries the
+// same id modulo 8, i.e. runs on one XCD, whose L2 then holds that shot's working set.
+//
+// Equations: see kernels_generic.hip (same update, same gradient and illumination terms).
+#include "mifwi_internal.hpp"
+
+namespace mifwi {
+
+__device__ inline float fast_div(float a, float b)
+{
+    // reciprocal + one Newton step: relative error ~1e-7, far inside the parity budget
+    float r = __builtin_amdgcn_rcpf(b);
+    r = r * (2.0f - b * r);
+    return a * r;
+}
+
+template <int R, int TX, int TZ, bool GRAD>
+__global__ __launch_bounds__(256) void step2d_kernel(Step2DArgs a)
+{
+    constexpr int RZ = (R + 3) / 4 * 4;          // z halo in LDS, multiple of 4
+    constexpr int ROWF4 = (TZ + 2 * RZ) / 4;     // float4 per staged row
+    constexpr int P = tile2d_lds_pitch(TZ, R);   // LDS row pitch in floats
+    constexpr int TQ = TZ / 4;                   // threads per tile row
+    static_assert(TQ * TX == 256, "one float4 per thread");
+    __shared__ __attribute__((aligned(16))) float lds[(TX + 2 * R) * P];
+
+    const int tid = threadIdx.x;
+    const int ntile_blocks = a.ntx * a.ntz * a.nshots;
+    const int bid = blockIdx.x;
+
+    if (bid >= ntile_blocks) {
+        // ---- interpolation role -------------------------------------------------------------
+        const int j = bid - ntile_blocks;
+        const int shot = j % a.nshots;
+        const int pnt = (j / a.nshots) * 256 + tid;
+        if (pnt >= a.itp_npoint) return;
+        const int tab = a.itp_per_shot ? shot : 0;
+        const int32_t *idx = a.pt_idx + ((long)tab * a.itp_npoint + pnt) * 4;
+        const float *w = a.pt_w + ((long)tab * a.itp_npoint + pnt) * 4;
+        const float *f = a.cur + (long)shot * a.shot_stride;
+        float sum = 0.f;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) sum += w[c] * f[idx[c]];
+        a.vals_out[((long)shot * a.nt + a.time) * a.itp_npoint + pnt] = sum;
+        return;
+    }
+
+    const int shot = bid % a.nshots;
+    const int tile = bid / a.nshots;
+    const int tile_x = tile / a.ntz, tile_z = tile - tile_x * a.ntz;
+    const int x0 = tile_x * TX, z0 = tile_z * TZ;
+    const float *cur = a.cur + (long)shot * a.shot_stride + a.off0;
+
+    // ---- stage the tile of `cur` (with halo) in LDS ---------------------------------------------
+    for (int c = tid; c < (TX + 2 * R) * ROWF4; c += 256) {
+        const int row = c / ROWF4, q = c - row * ROWF4;
+        const int gx = x0 - R + row;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (gx < a.n1 + R) v = *reinterpret_cast<const float4 *>(cur + (long)gx * a.s1 + (z0 - RZ + 4 * q));
+        *reinterpret_cast<float4 *>(&lds[row * P + 4 * q]) = v;
+    }
+    __syncthreads();
+
+    const int tx = tid / TQ, tq = tid - tx * TQ;
+    const int x = x0 + tx, z = z0 + 4 * tq;
+    const bool live = (x < a.n1) && (z < a.n2);
+    if (live) {
+        const float *ctr = &lds[(tx + R) * P + RZ + 4 * tq];
+        // z line: floats -RZ .. 4+RZ-1 around the 4 centre points
+        float f[4 + 2 * RZ];
+#pragma unroll
+        for (int q = 0; q < (4 + 2 * RZ) / 4; ++q) {
+            const float4 v = *reinterpret_cast<const float4 *>(ctr - RZ + 4 * q);
+            f[4 * q + 0] = v.x, f[4 * q + 1] = v.y, f[4 * q + 2] = v.z, f[4 * q + 3] = v.w;
+        }
+        float lap[4], uc[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            uc[i] = f[RZ + i];
+            lap[i] = a.c0 * uc[i];
+        }
+#pragma unroll
+        for (int k = 1; k <= R; ++k) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) lap[i] += a.cz[k] * (f[RZ + i - k] + f[RZ + i + k]);
+        }
+#pragma unroll
+        for (int k = 1; k <= R; ++k) {
+            const float4 lo = *reinterpret_cast<const float4 *>(ctr - k * P);
+            const float4 hi = *reinterpret_cast<const float4 *>(ctr + k * P);
+            lap[0] += a.cx[k] * (lo.x + hi.x);
+            lap[1] += a.cx[k] * (lo.y + hi.y);
+            lap[2] += a.cx[k] * (lo.z + hi.z);
+            lap[3] += a.cx[k] * (lo.w + hi.w);
+        }
+        const long p = a.off0 + (long)x * a.s1 + z;
+        const long ps = (long)shot * a.shot_stride + p;
+        const float4 m4 = *reinterpret_cast<const float4 *>(a.m + p);
+        const float4 e4 = *reinterpret_cast<const float4 *>(a.eta + p);
+        const float4 o4 = *reinterpret_cast<const float4 *>(a.old + ps);
+        const float mm[4] = {m4.x, m4.y, m4.z, m4.w}, ee[4] = {e4.x, e4.y, e4.z, e4.w},
+                    oo[4] = {o4.x, o4.y, o4.z, o4.w};
+        float res[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float ed = ee[i] * a.dt;
+            res[i] = fast_div(a.dt2 * lap[i] + 2.0f * mm[i] * uc[i] - mm[i] * oo[i] + ed * uc[i], mm[i] + ed);
+        }
+        const bool full = (z + 3 < a.n2);
+        if (full) {
+            *reinterpret_cast<float4 *>(a.out + ps) = make_float4(res[0], res[1], res[2], res[3]);
+        } else {
+            for (int i = 0; i < 4; ++i)
+                if (z + i < a.n2) a.out[ps + i] = res[i];
+        }
+        if (GRAD) {
+            const long qs = (long)shot * a.u_shot_stride + p;
+            const long gs = (long)shot * a.g_shot_stride + p;
+            const float4 um4 = *reinterpret_cast<const float4 *>(a.um + qs);
+            const float4 u04 = *reinterpret_cast<const float4 *>(a.uc + qs);
+            const float4 up4 = *reinterpret_cast<const float4 *>(a.up + qs);
+            const float um[4] = {um4.x, um4.y, um4.z, um4.w}, u0[4] = {u04.x, u04.y, u04.z, u04.w},
+                        up[4] = {up4.x, up4.y, up4.z, up4.w};
+            float g[4], il[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                g[i] = -((um[i] - 2.0f * u0[i] + up[i]) * a.inv_dt2) * uc[i];
+                il[i] = u0[i] * u0[i] + (a.first ? up[i] * up[i] : 0.0f);
+            }
+            if (full) {
+                float4 gv = *reinterpret_cast<const float4 *>(a.grad + gs);
+                gv.x += g[0], gv.y += g[1], gv.z += g[2], gv.w += g[3];
+                *reinterpret_cast<float4 *>(a.grad + gs) = gv;
+                if (a.illum) {
+                    float4 iv = *reinterpret_cast<const float4 *>(a.illum + gs);
+                    iv.x += il[0], iv.y += il[1], iv.z += il[2], iv.w += il[3];
+                    *reinterpret_cast<float4 *>(a.illum + gs) = iv;
+                }
+            } else {
+                for (int i = 0; i < 4; ++i)
+                    if (z + i < a.n2) {
+                        a.grad[gs + i] += g[i];
+                        if (a.illum) a.illum[gs + i] += il[i];
+                    }
+            }
+        }
+    }
+
+    // ---- injection into the cells this tile owns ----------------------------------------------
+    if (a.tile_ptr) {
+        const int tab = a.inj_per_shot ? shot : 0;
+        const int32_t *tp = a.tile_ptr + (long)tab * (a.ntx * a.ntz + 1);
+        const int beg = tp[tile], end = tp[tile + 1];
+        if (beg < end) {  // block-uniform
+            __syncthreads();  // the tile's stores to `out` are complete and visible to the block
+            const int32_t *ptr = a.uc_ptr + (long)tab * (a.inj_kmax + 1);
+            const int32_t *ep = a.e_point + (long)tab * a.inj_kmax;
+            const float *ew = a.e_w + (long)tab * a.inj_kmax;
+            const float *vals = a.vals_inj + ((long)shot * a.nt + a.time) * a.inj_npoint;
+            for (int j = beg + tid; j < end; j += 256) {
+                const int kk = a.tile_cells[(long)tab * a.inj_kmax + j];
+                float sum = 0.f;
+                for (int e = ptr[kk]; e < ptr[kk + 1]; ++e) sum += ew[e] * vals[ep[e]];
+                const long cell = a.uc_cell[(long)tab * a.inj_kmax + kk];
+                a.out[(long)shot * a.shot_stride + cell] += sum * a.dt2 / a.m[cell];
+            }
+        }
+    }
+}
+
+template <int R, int TX, int TZ>
+static int launch_rt(const Plan &p, const Step2DArgs &a, int nblocks)
+{
+    if (a.um)
+        hipLaunchKernelGGL((step2d_kernel<R, TX, TZ, true>), dim3(nblocks), dim3(256), 0, p.stream, a);
+    else
+        hipLaunchKernelGGL((step2d_kernel<R, TX, TZ, false>), dim3(nblocks), dim3(256), 0, p.stream, a);
+    MIFWI_HIP(hipGetLastError());
+    return MIFWI_OK;
+}
+
+template <int R>
+static int launch_r(const Plan &p, const Step2DArgs &a, int nblocks)
+{
+    if (p.tile_tz == 64) return launch_rt<R, 16, 64>(p, a, nblocks);
+    return launch_rt<R, 32, 32>(p, a, nblocks);
+}
+
+int launch_step2d(const Plan &p, const Step2DArgs &a)
+{
+    const int nblocks = a.ntx * a.ntz * a.nshots + (a.pt_idx ? ((a.itp_npoint + 255) / 256) * a.nshots : 0);
+    switch (p.L.R) {
+        case 1: return launch_r<1>(p, a, nblocks);
+        case 2: return launch_r<2>(p, a, nblocks);
+        case 3: return launch_r<3>(p, a, nblocks);
+        case 4: return launch_r<4>(p, a, nblocks);
+        case 5: return launch_r<5>(p, a, nblocks);
+        case 6: return launch_r<6>(p, a, nblocks);
+        case 7: return launch_r<7>(p, a, nblocks);
+        case 8: return launch_r<8>(p, a, nblocks);
+    }
+    set_error("unsupported stencil radius");
+    return MIFWI_EINVAL;
+}
+
+}  // namespace mifwi

@@ -56,9 +56,9 @@ static int make_layout(const mifwi_config &c, Layout &L)
     const long first = (long)L.halo[0] * L.s0 + (long)L.halo[1] * L.s1 + L.zl;  // unshifted index of (0,0,0)
     const long shift = (32 - first % 32) % 32;
     L.off0 = first + shift;
-    // one extra row of slack so that vector reads that start inside the right z halo of the
-    // last row stay inside the allocation
-    L.field = round_up(body + shift + 64, 32);
+    // slack so that tile staging reads that run past the end of the last row (into what is the
+    // zero left halo of the next row everywhere else) stay inside the allocation
+    L.field = round_up(body + shift + 256, 32);
     L.ngrid = (long)L.n[0] * L.n[1] * L.n[2];
     if (L.field > 0x7fffffffL) return -1;  // sparse tables use 32-bit offsets
     return 0;
@@ -120,6 +120,8 @@ static void free_sparse(SparseSet &s)
     dev_free(s.uc_count);
     dev_free(s.e_point);
     dev_free(s.e_w);
+    dev_free(s.tile_ptr);
+    dev_free(s.tile_cells);
     s = SparseSet{};
 }
 
@@ -197,6 +199,9 @@ static int build_sparse(Plan &p, SparseSet &S, const T *coords /* [tables][npoin
     std::vector<int32_t> uc_cell((size_t)tables * S.kmax, (int32_t)L.off0), uc_ptr((size_t)tables * (S.kmax + 1), 0),
         uc_count(tables, 0), e_point((size_t)tables * S.kmax, 0);
     std::vector<T> e_w((size_t)tables * S.kmax, T(0));
+    const int ntiles = p.kind == 1 ? p.ntx * p.ntz : 0;
+    S.ntiles = ntiles;
+    std::vector<int32_t> tile_ptr((size_t)tables * (ntiles + 1), 0), tile_cells((size_t)tables * S.kmax, 0);
     struct Entry {
         int32_t cell;
         int32_t point;
@@ -257,6 +262,30 @@ static int build_sparse(Plan &p, SparseSet &S, const T *coords /* [tables][npoin
         ptrp[nu] = (int32_t)ent.size();
         uc_count[t] = nu;
         S.max_count = std::max(S.max_count, nu);
+        if (ntiles) {
+            // group the unique cells by owning tile (stable: ascending cell order inside a tile)
+            std::vector<std::pair<int32_t, int32_t>> owner(nu);
+            for (int u = 0; u < nu; ++u) {
+                const long rel = (long)cellp[u] - L.off0;
+                const int i1 = (int)(rel / L.s1), i2 = (int)(rel % L.s1);
+                owner[u] = {(i1 / p.tile_tx) * p.ntz + (i2 / p.tile_tz), u};
+            }
+            std::stable_sort(owner.begin(), owner.end(),
+                             [](const std::pair<int32_t, int32_t> &a, const std::pair<int32_t, int32_t> &b) {
+                                 return a.first < b.first;
+                             });
+            int32_t *tp = &tile_ptr[(size_t)t * (ntiles + 1)];
+            int32_t *tc = &tile_cells[(size_t)t * S.kmax];
+            int u = 0;
+            for (int tl = 0; tl < ntiles; ++tl) {
+                tp[tl] = u;
+                while (u < nu && owner[u].first == tl) {
+                    tc[u] = owner[u].second;
+                    ++u;
+                }
+            }
+            tp[ntiles] = nu;
+        }
     }
     int rc;
     auto up = [&](void **dst, const void *src, size_t bytes) -> int {
@@ -271,6 +300,10 @@ static int build_sparse(Plan &p, SparseSet &S, const T *coords /* [tables][npoin
     if ((rc = up((void **)&S.uc_count, uc_count.data(), uc_count.size() * 4))) return rc;
     if ((rc = up((void **)&S.e_point, e_point.data(), e_point.size() * 4))) return rc;
     if ((rc = up(&S.e_w, e_w.data(), e_w.size() * sizeof(T)))) return rc;
+    if (ntiles) {
+        if ((rc = up((void **)&S.tile_ptr, tile_ptr.data(), tile_ptr.size() * 4))) return rc;
+        if ((rc = up((void **)&S.tile_cells, tile_cells.data(), tile_cells.size() * 4))) return rc;
+    }
     // the host vectors die at return: make sure the uploads have been consumed
     MIFWI_HIP(hipStreamSynchronize(p.stream));
     return MIFWI_OK;
@@ -317,6 +350,16 @@ static int create(const mifwi_config *cfg, mifwi_plan **out)
     if (make_layout(*cfg, p->L)) {
         delete p;
         return fail(MIFWI_EINVAL, "grid too large for 32-bit sparse offsets");
+    }
+    if (cfg->ndim == 2 && cfg->dtype == MIFWI_F32 && !(cfg->flags & MIFWI_FLAG_GENERIC)) {
+        // tiled fast path: pick the tile shape that wastes fewer threads on this grid
+        const int n1 = p->L.n[1], n2 = p->L.n[2];
+        auto waste = [&](int tx, int tz) { return (double)((n1 + tx - 1) / tx * tx) * ((n2 + tz - 1) / tz * tz); };
+        p->kind = 1;
+        if (waste(16, 64) <= waste(32, 32)) p->tile_tx = 16, p->tile_tz = 64;
+        else p->tile_tx = 32, p->tile_tz = 32;
+        p->ntx = (n1 + p->tile_tx - 1) / p->tile_tx;
+        p->ntz = (n2 + p->tile_tz - 1) / p->tile_tz;
     }
     auto bail = [&](int code) {
         destroy(p);
@@ -411,7 +454,7 @@ static void fill_stats(Plan &p, double ms, double steps, int nshots, double byte
     p.stats.gpointss = ms > 0 ? p.stats.points / (ms * 1e-3) / 1e9 : 0.0;
     p.stats.algorithmic_bytes = p.stats.points * bytes_per_point * (p.esize / 4.0);
     p.stats.launches = launches;
-    p.stats.kernel_kind = 0;
+    p.stats.kernel_kind = p.kind;
     p.stats.device_bytes = p.device_bytes;
 }
 
@@ -426,6 +469,57 @@ static int upload_wavelet(Plan &p, int nshots, const void *wavelet, int per_shot
     for (int s = 0; s < nshots; ++s)
         if ((rc = copy_any(p, (char *)p.d_wavelet + s * one, wavelet, one))) return rc;
     return MIFWI_OK;
+}
+
+// constants of the tiled 2-D kernel
+static Step2DArgs base2d(const Plan &p, int nshots)
+{
+    Step2DArgs a{};
+    double w[kMaxR + 1];
+    fd2_weights(p.L.R, w);
+    const double ihx = 1.0 / (p.cfg.spacing[0] * p.cfg.spacing[0]), ihz = 1.0 / (p.cfg.spacing[1] * p.cfg.spacing[1]);
+    a.c0 = (float)(w[0] * ihx + w[0] * ihz);
+    for (int j = 0; j <= p.L.R; ++j) {
+        a.cx[j] = (float)(w[j] * ihx);
+        a.cz[j] = (float)(w[j] * ihz);
+    }
+    a.dt = (float)p.cfg.dt;
+    a.dt2 = a.dt * a.dt;
+    a.inv_dt2 = 1.0f / a.dt2;
+    a.n1 = p.L.n[1];
+    a.n2 = p.L.n[2];
+    a.s1 = p.L.s1;
+    a.off0 = p.L.off0;
+    a.ntx = p.ntx;
+    a.ntz = p.ntz;
+    a.nshots = nshots;
+    a.m = (const float *)p.m;
+    a.eta = (const float *)p.eta;
+    a.nt = p.cfg.nt;
+    return a;
+}
+static void set_inject(Step2DArgs &a, const SparseSet &S, const void *vals)
+{
+    if (S.npoint <= 0 || S.max_count <= 0) return;
+    a.uc_cell = S.uc_cell;
+    a.uc_ptr = S.uc_ptr;
+    a.e_point = S.e_point;
+    a.e_w = (const float *)S.e_w;
+    a.tile_ptr = S.tile_ptr;
+    a.tile_cells = S.tile_cells;
+    a.inj_kmax = S.kmax;
+    a.inj_npoint = S.npoint;
+    a.inj_per_shot = S.per_shot;
+    a.vals_inj = (const float *)vals;
+}
+static void set_interp(Step2DArgs &a, const SparseSet &S, void *vals_out)
+{
+    if (S.npoint <= 0) return;
+    a.pt_idx = S.pt_idx;
+    a.pt_w = (const float *)S.pt_w;
+    a.itp_npoint = S.npoint;
+    a.itp_per_shot = S.per_shot;
+    a.vals_out = (float *)vals_out;
 }
 
 // forward time loop on data already resident on the device (d_wavelet -> d_rec)
@@ -458,7 +552,21 @@ static int run_forward(Plan &p, int nshots, int save)
     auto lvl = [&](int t) { return base + (long)(save ? t : t % 3) * L.field; };
     MIFWI_HIP(hipEventRecord(p.ev0, p.stream));
     int launches = 0;
-    for (int time = 1; time <= nt - 2; ++time) {
+    if (p.kind == 1) {
+        Step2DArgs a = base2d(p, nshots);
+        a.shot_stride = shot_stride;
+        set_inject(a, p.src, p.d_wavelet);
+        set_interp(a, p.rec, p.d_rec);
+        for (int time = 1; time <= nt - 2; ++time) {
+            a.cur = (const float *)lvl(time);
+            a.old = (const float *)lvl(time - 1);
+            a.out = (float *)lvl(time + 1);
+            a.time = time;
+            if ((rc = launch_step2d(p, a))) return rc;
+            ++launches;
+        }
+    }
+    for (int time = 1; p.kind == 0 && time <= nt - 2; ++time) {
         StepPtrs<T> sp{lvl(time), lvl(time - 1), lvl(time + 1), shot_stride, (const T *)p.m, (const T *)p.eta};
         GradPtrs<T> gp{};
         if ((rc = launch_step_generic<T>(p, k, sp, gp, nshots))) return rc;
@@ -522,7 +630,31 @@ static int run_backward(Plan &p, int nshots, bool with_grad, bool with_illum)
     const long sv_stride = (long)nt * L.field;
     MIFWI_HIP(hipEventRecord(p.ev0, p.stream));
     int launches = 0;
-    for (int time = nt - 2; time >= 1; --time) {
+    if (p.kind == 1) {
+        Step2DArgs a = base2d(p, nshots);
+        a.shot_stride = shot_stride;
+        set_inject(a, p.rec, p.d_res);
+        if (!with_grad) set_interp(a, p.src, p.d_srca);
+        for (int time = nt - 2; time >= 1; --time) {
+            a.cur = (const float *)lvl(time);
+            a.old = (const float *)lvl(time + 1);
+            a.out = (float *)lvl(time - 1);
+            a.time = time;
+            if (with_grad) {
+                a.um = (const float *)sv + (long)(time - 1) * L.field;
+                a.uc = (const float *)sv + (long)time * L.field;
+                a.up = (const float *)sv + (long)(time + 1) * L.field;
+                a.u_shot_stride = sv_stride;
+                a.grad = (float *)p.d_grad;
+                a.illum = with_illum ? (float *)p.d_illum : nullptr;
+                a.g_shot_stride = L.field;
+                a.first = (time == nt - 2);
+            }
+            if ((rc = launch_step2d(p, a))) return rc;
+            ++launches;
+        }
+    }
+    for (int time = nt - 2; p.kind == 0 && time >= 1; --time) {
         StepPtrs<T> sp{lvl(time), lvl(time + 1), lvl(time - 1), shot_stride, (const T *)p.m, (const T *)p.eta};
         GradPtrs<T> gp{};
         if (with_grad) {

@@ -69,6 +69,10 @@ struct SparseSet {
     int32_t *e_point = nullptr;  // [tables][kmax]
     void *e_w = nullptr;         // [tables][kmax] (T)
     int max_count = 0;           // max unique cells over tables (host copy)
+    // unique cells grouped by the tile (of the tiled kernels) that owns them
+    int ntiles = 0;
+    int32_t *tile_ptr = nullptr;   // [tables][ntiles+1] ranges into tile_cells
+    int32_t *tile_cells = nullptr; // [tables][kmax] indices into uc_cell / uc_ptr
 };
 
 struct Plan {
@@ -103,6 +107,10 @@ struct Plan {
     size_t dense_elems = 0;
     double *d_partial = nullptr;             // misfit partial sums
     double *d_fval = nullptr;                // [max_shots]
+
+    // tiled fast path (2-D float32): tile shape and count; kind 0 = generic kernels only
+    int kind = 0;
+    int tile_tx = 0, tile_tz = 0, ntx = 0, ntz = 0;
 
     mifwi_stats stats{};
     int64_t device_bytes = 0;
@@ -175,5 +183,41 @@ int launch_pack(const Plan &p, const T *dense, T *haloed, long shot_stride, int 
 template <typename T>
 int launch_l2_misfit(const Plan &p, const T *syn, const T *obs, T *res, long n_per_shot, int nshots,
                      double *partial, double *fval);
+
+// ---- tiled 2-D fast path (kernels_tiled2d.hip) -------------------------------------------------
+// LDS row pitch (floats) of a staged tile: a multiple of 64 so that the rows a wave touches with
+// one ds_read_b128 fall on disjoint bank groups.
+constexpr int tile2d_lds_pitch(int TZ, int R) { return ((TZ + 2 * ((R + 3) / 4 * 4)) + 63) / 64 * 64; }
+
+struct Step2DArgs {
+    const float *cur, *old;
+    float *out;
+    long shot_stride;
+    const float *m, *eta;
+    float c0, cx[kMaxR + 1], cz[kMaxR + 1];
+    float dt, dt2, inv_dt2;
+    int n1, n2;
+    long s1, off0;
+    int ntx, ntz, nshots;
+    // gradient (um == nullptr: plain propagation)
+    const float *um, *uc, *up;
+    long u_shot_stride;
+    float *grad, *illum;
+    long g_shot_stride;
+    int first;
+    // injection (tile_ptr == nullptr: none)
+    const int32_t *uc_cell, *uc_ptr, *e_point;
+    const float *e_w;
+    const int32_t *tile_ptr, *tile_cells;
+    int inj_kmax, inj_npoint, inj_per_shot;
+    const float *vals_inj;
+    // interpolation of `cur` (pt_idx == nullptr: none)
+    const int32_t *pt_idx;
+    const float *pt_w;
+    int itp_npoint, itp_per_shot;
+    float *vals_out;
+    int time, nt;
+};
+int launch_step2d(const Plan &p, const Step2DArgs &a);
 
 }  // namespace mifwi

@@ -59,14 +59,23 @@ def _check_case(mifwi, case, flags=0):
     plan.close()
 
 
+# flags 0: tiled fast path where available; 4 (MIFWI_FLAG_GENERIC): untiled reference kernels
+@pytest.mark.parametrize("flags", [0, 4])
 @pytest.mark.parametrize("so", [2, 4, 8, 16])
-def test_2d_orders(mifwi, so):
-    _check_case(mifwi, Case((45, 38), (10.0, 12.5), nbl=9, space_order=so, nt=140, nshots=2, nrec=13))
+def test_2d_orders(mifwi, so, flags):
+    _check_case(mifwi, Case((45, 38), (10.0, 12.5), nbl=9, space_order=so, nt=140, nshots=2, nrec=13), flags)
 
 
+@pytest.mark.parametrize("flags", [0, 4])
 @pytest.mark.parametrize("so", [6, 10, 12, 14])
-def test_2d_other_orders(mifwi, so):
-    _check_case(mifwi, Case((31, 29), (10.0, 10.0), nbl=8, space_order=so, nt=90, nshots=1, nrec=7, seed=3))
+def test_2d_other_orders(mifwi, so, flags):
+    _check_case(mifwi, Case((31, 29), (10.0, 10.0), nbl=8, space_order=so, nt=90, nshots=1, nrec=7, seed=3), flags)
+
+
+@pytest.mark.parametrize("shape", [(75, 83), (130, 41), (20, 200)])
+def test_2d_many_tiles_ragged(mifwi, shape):
+    # several tiles per dimension, widths that are not multiples of 4 / of the tile, 3 shots, dense receivers
+    _check_case(mifwi, Case(shape, (10.0, 10.0), nbl=9, space_order=8, nt=120, nshots=3, nrec=57, seed=13))
 
 
 @pytest.mark.parametrize("so", [4, 8, 16])
