@@ -8,10 +8,10 @@
 //     z line once, 2R row neighbours), reads old/m/eta with one aligned 16-byte load each and
 //     stores 16 bytes.  The gradient variant also reads the three saved forward levels and
 //     read-modify-writes grad (and illum).
-//   * after its stores, a tile block adds the injected source/receiver terms for the grid cells it
-//     owns (per-tile CSR built on the host: one thread per cell, fixed summation order, no
-//     atomics).
-//   * extra blocks at the end of the grid interpolate the field being read at the receiver (or
+//   * a tile block that owns cells touched by sources/receivers (per-tile slot table built on the
+//     host) forms their injected terms in LDS while its stencil loads are in flight -- one thread per
+//     cell, fixed summation order, no atomics -- and the owning threads add them before storing.
+//   * extra blocks at the start of the grid interpolate the field being read at the receiver (or
 //     source) positions.
 // Block ids are dealt shot-fastest: with a multiple of 8 shots every block of a shot carries the
 // same id modulo 8, i.e. runs on one XCD, whose L2 then holds that shot's working set.
@@ -36,49 +36,98 @@ __global__ __launch_bounds__(256) void step2d_kernel(Step2DArgs a)
     constexpr int ROWF4 = (TZ + 2 * RZ) / 4;     // float4 per staged row
     constexpr int P = tile2d_lds_pitch(TZ, R);   // LDS row pitch in floats
     constexpr int TQ = TZ / 4;                   // threads per tile row
+    constexpr int NSTAGE = ((TX + 2 * R) * ROWF4 + 255) / 256;  // staged float4 per thread
     static_assert(TQ * TX == 256, "one float4 per thread");
     __shared__ __attribute__((aligned(16))) float lds[(TX + 2 * R) * P];
+    __shared__ __attribute__((aligned(16))) float acc[TX * TZ];   // injected terms of this tile
 
     const int tid = threadIdx.x;
-    const int ntile_blocks = a.ntx * a.ntz * a.nshots;
-    const int bid = blockIdx.x;
+    const int nitp_blocks = a.pt_idx ? ((a.itp_npoint + 255) / 256) * a.nshots : 0;
+    int bid = blockIdx.x;
 
-    if (bid >= ntile_blocks) {
-        // ---- interpolation role -------------------------------------------------------------
-        const int j = bid - ntile_blocks;
-        const int shot = j % a.nshots;
-        const int pnt = (j / a.nshots) * 256 + tid;
+    if (bid < nitp_blocks) {
+        // ---- interpolation role (first in the grid: two dependent loads, start them early) -----
+        const int shot = a.shot0 + bid % a.nshots;
+        const int pnt = (bid / a.nshots) * 256 + tid;
         if (pnt >= a.itp_npoint) return;
         const int tab = a.itp_per_shot ? shot : 0;
-        const int32_t *idx = a.pt_idx + ((long)tab * a.itp_npoint + pnt) * 4;
-        const float *w = a.pt_w + ((long)tab * a.itp_npoint + pnt) * 4;
+        const int4 idx = *reinterpret_cast<const int4 *>(a.pt_idx + ((long)tab * a.itp_npoint + pnt) * 4);
+        const float4 w = *reinterpret_cast<const float4 *>(a.pt_w + ((long)tab * a.itp_npoint + pnt) * 4);
         const float *f = a.cur + (long)shot * a.shot_stride;
-        float sum = 0.f;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) sum += w[c] * f[idx[c]];
+        const float sum = w.x * f[idx.x] + w.y * f[idx.y] + w.z * f[idx.z] + w.w * f[idx.w];
         a.vals_out[((long)shot * a.nt + a.time) * a.itp_npoint + pnt] = sum;
         return;
     }
+    bid -= nitp_blocks;
 
-    const int shot = bid % a.nshots;
+    const int shot = a.shot0 + bid % a.nshots;
     const int tile = bid / a.nshots;
     const int tile_x = tile / a.ntz, tile_z = tile - tile_x * a.ntz;
     const int x0 = tile_x * TX, z0 = tile_z * TZ;
     const float *cur = a.cur + (long)shot * a.shot_stride + a.off0;
-
-    // ---- stage the tile of `cur` (with halo) in LDS ---------------------------------------------
-    for (int c = tid; c < (TX + 2 * R) * ROWF4; c += 256) {
-        const int row = c / ROWF4, q = c - row * ROWF4;
-        const int gx = x0 - R + row;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (gx < a.n1 + R) v = *reinterpret_cast<const float4 *>(cur + (long)gx * a.s1 + (z0 - RZ + 4 * q));
-        *reinterpret_cast<float4 *>(&lds[row * P + 4 * q]) = v;
-    }
-    __syncthreads();
-
     const int tx = tid / TQ, tq = tid - tx * TQ;
     const int x = x0 + tx, z = z0 + 4 * tq;
     const bool live = (x < a.n1) && (z < a.n2);
+    const long p = a.off0 + (long)x * a.s1 + z;
+    const long ps = (long)shot * a.shot_stride + p;
+
+    // ---- issue every global load up front: they share one memory round trip -------------------
+    const int inj_tab = a.inj_per_shot ? shot : 0;
+    const int ninj = a.slot_count ? a.slot_count[(long)inj_tab * (a.ntx * a.ntz) + tile] : 0;  // block-uniform
+    float4 stage[NSTAGE];
+#pragma unroll
+    for (int i = 0; i < NSTAGE; ++i) {
+        const int c = tid + i * 256;
+        const int row = c / ROWF4, q = c - row * ROWF4;
+        const int gx = x0 - R + row;
+        stage[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (c < (TX + 2 * R) * ROWF4 && gx < a.n1 + R)
+            stage[i] = *reinterpret_cast<const float4 *>(cur + (long)gx * a.s1 + (z0 - RZ + 4 * q));
+    }
+    float4 m4 = make_float4(1.f, 1.f, 1.f, 1.f), e4 = make_float4(0.f, 0.f, 0.f, 0.f), o4 = e4;
+    float4 um4 = e4, u04 = e4, up4 = e4, gv = e4, iv = e4;
+    const long qs = (long)shot * a.u_shot_stride + p;
+    const long gs = (long)shot * a.g_shot_stride + p;
+    if (live) {
+        m4 = *reinterpret_cast<const float4 *>(a.m + p);
+        e4 = *reinterpret_cast<const float4 *>(a.eta + p);
+        o4 = *reinterpret_cast<const float4 *>(a.old + ps);
+        if (GRAD) {
+            um4 = *reinterpret_cast<const float4 *>(a.um + qs);
+            u04 = *reinterpret_cast<const float4 *>(a.uc + qs);
+            up4 = *reinterpret_cast<const float4 *>(a.up + qs);
+            gv = *reinterpret_cast<const float4 *>(a.grad + gs);
+            if (a.illum) iv = *reinterpret_cast<const float4 *>(a.illum + gs);
+        }
+    }
+
+    // ---- injected terms of the cells this tile owns (rare: block-uniform branch) ---------------
+    if (ninj > 0) {
+        *reinterpret_cast<float4 *>(&acc[4 * tid]) = make_float4(0.f, 0.f, 0.f, 0.f);
+        __syncthreads();
+        const float *vals = a.vals_inj + ((long)shot * a.nt + a.time) * a.inj_npoint;
+        const long tbase = ((long)inj_tab * (a.ntx * a.ntz) + tile) * a.inj_cap;
+        for (int j = tid; j < ninj; j += 256) {
+            const int local = a.slot_local[tbase + j];
+            const int32_t *ep = a.slot_ep + (tbase + j) * a.inj_maxe;
+            const float *ew = a.slot_ew + (tbase + j) * a.inj_maxe;
+            float sum = 0.f;
+            for (int e = 0; e < a.inj_maxe; ++e) sum += ew[e] * vals[ep[e]];
+            const int lx = local / TZ, lz = local - lx * TZ;
+            const float mc = a.m[a.off0 + (long)(x0 + lx) * a.s1 + (z0 + lz)];
+            acc[local] = sum * a.dt2 / mc;
+        }
+    }
+
+    // ---- stage the tile of `cur` (with halo) in LDS --------------------------------------------
+#pragma unroll
+    for (int i = 0; i < NSTAGE; ++i) {
+        const int c = tid + i * 256;
+        const int row = c / ROWF4, q = c - row * ROWF4;
+        if (c < (TX + 2 * R) * ROWF4) *reinterpret_cast<float4 *>(&lds[row * P + 4 * q]) = stage[i];
+    }
+    __syncthreads();
+
     if (live) {
         const float *ctr = &lds[(tx + R) * P + RZ + 4 * tq];
         // z line: floats -RZ .. 4+RZ-1 around the 4 centre points
@@ -108,11 +157,6 @@ __global__ __launch_bounds__(256) void step2d_kernel(Step2DArgs a)
             lap[2] += a.cx[k] * (lo.z + hi.z);
             lap[3] += a.cx[k] * (lo.w + hi.w);
         }
-        const long p = a.off0 + (long)x * a.s1 + z;
-        const long ps = (long)shot * a.shot_stride + p;
-        const float4 m4 = *reinterpret_cast<const float4 *>(a.m + p);
-        const float4 e4 = *reinterpret_cast<const float4 *>(a.eta + p);
-        const float4 o4 = *reinterpret_cast<const float4 *>(a.old + ps);
         const float mm[4] = {m4.x, m4.y, m4.z, m4.w}, ee[4] = {e4.x, e4.y, e4.z, e4.w},
                     oo[4] = {o4.x, o4.y, o4.z, o4.w};
         float res[4];
@@ -120,6 +164,10 @@ __global__ __launch_bounds__(256) void step2d_kernel(Step2DArgs a)
         for (int i = 0; i < 4; ++i) {
             const float ed = ee[i] * a.dt;
             res[i] = fast_div(a.dt2 * lap[i] + 2.0f * mm[i] * uc[i] - mm[i] * oo[i] + ed * uc[i], mm[i] + ed);
+        }
+        if (ninj > 0) {
+            const float4 add = *reinterpret_cast<const float4 *>(&acc[4 * tid]);
+            res[0] += add.x, res[1] += add.y, res[2] += add.z, res[3] += add.w;
         }
         const bool full = (z + 3 < a.n2);
         if (full) {
@@ -129,90 +177,59 @@ __global__ __launch_bounds__(256) void step2d_kernel(Step2DArgs a)
                 if (z + i < a.n2) a.out[ps + i] = res[i];
         }
         if (GRAD) {
-            const long qs = (long)shot * a.u_shot_stride + p;
-            const long gs = (long)shot * a.g_shot_stride + p;
-            const float4 um4 = *reinterpret_cast<const float4 *>(a.um + qs);
-            const float4 u04 = *reinterpret_cast<const float4 *>(a.uc + qs);
-            const float4 up4 = *reinterpret_cast<const float4 *>(a.up + qs);
             const float um[4] = {um4.x, um4.y, um4.z, um4.w}, u0[4] = {u04.x, u04.y, u04.z, u04.w},
                         up[4] = {up4.x, up4.y, up4.z, up4.w};
-            float g[4], il[4];
+            float g[4] = {gv.x, gv.y, gv.z, gv.w}, il[4] = {iv.x, iv.y, iv.z, iv.w};
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                g[i] = -((um[i] - 2.0f * u0[i] + up[i]) * a.inv_dt2) * uc[i];
-                il[i] = u0[i] * u0[i] + (a.first ? up[i] * up[i] : 0.0f);
+                g[i] += -((um[i] - 2.0f * u0[i] + up[i]) * a.inv_dt2) * uc[i];
+                il[i] += u0[i] * u0[i] + (a.first ? up[i] * up[i] : 0.0f);
             }
             if (full) {
-                float4 gv = *reinterpret_cast<const float4 *>(a.grad + gs);
-                gv.x += g[0], gv.y += g[1], gv.z += g[2], gv.w += g[3];
-                *reinterpret_cast<float4 *>(a.grad + gs) = gv;
-                if (a.illum) {
-                    float4 iv = *reinterpret_cast<const float4 *>(a.illum + gs);
-                    iv.x += il[0], iv.y += il[1], iv.z += il[2], iv.w += il[3];
-                    *reinterpret_cast<float4 *>(a.illum + gs) = iv;
-                }
+                *reinterpret_cast<float4 *>(a.grad + gs) = make_float4(g[0], g[1], g[2], g[3]);
+                if (a.illum) *reinterpret_cast<float4 *>(a.illum + gs) = make_float4(il[0], il[1], il[2], il[3]);
             } else {
                 for (int i = 0; i < 4; ++i)
                     if (z + i < a.n2) {
-                        a.grad[gs + i] += g[i];
-                        if (a.illum) a.illum[gs + i] += il[i];
+                        a.grad[gs + i] = g[i];
+                        if (a.illum) a.illum[gs + i] = il[i];
                     }
-            }
-        }
-    }
-
-    // ---- injection into the cells this tile owns ----------------------------------------------
-    if (a.tile_ptr) {
-        const int tab = a.inj_per_shot ? shot : 0;
-        const int32_t *tp = a.tile_ptr + (long)tab * (a.ntx * a.ntz + 1);
-        const int beg = tp[tile], end = tp[tile + 1];
-        if (beg < end) {  // block-uniform
-            __syncthreads();  // the tile's stores to `out` are complete and visible to the block
-            const int32_t *ptr = a.uc_ptr + (long)tab * (a.inj_kmax + 1);
-            const int32_t *ep = a.e_point + (long)tab * a.inj_kmax;
-            const float *ew = a.e_w + (long)tab * a.inj_kmax;
-            const float *vals = a.vals_inj + ((long)shot * a.nt + a.time) * a.inj_npoint;
-            for (int j = beg + tid; j < end; j += 256) {
-                const int kk = a.tile_cells[(long)tab * a.inj_kmax + j];
-                float sum = 0.f;
-                for (int e = ptr[kk]; e < ptr[kk + 1]; ++e) sum += ew[e] * vals[ep[e]];
-                const long cell = a.uc_cell[(long)tab * a.inj_kmax + kk];
-                a.out[(long)shot * a.shot_stride + cell] += sum * a.dt2 / a.m[cell];
             }
         }
     }
 }
 
 template <int R, int TX, int TZ>
-static int launch_rt(const Plan &p, const Step2DArgs &a, int nblocks)
+static int launch_rt(const Plan &p, const Step2DArgs &a, int nblocks, hipStream_t stream)
 {
     if (a.um)
-        hipLaunchKernelGGL((step2d_kernel<R, TX, TZ, true>), dim3(nblocks), dim3(256), 0, p.stream, a);
+        hipLaunchKernelGGL((step2d_kernel<R, TX, TZ, true>), dim3(nblocks), dim3(256), 0, stream, a);
     else
-        hipLaunchKernelGGL((step2d_kernel<R, TX, TZ, false>), dim3(nblocks), dim3(256), 0, p.stream, a);
+        hipLaunchKernelGGL((step2d_kernel<R, TX, TZ, false>), dim3(nblocks), dim3(256), 0, stream, a);
     MIFWI_HIP(hipGetLastError());
     return MIFWI_OK;
 }
 
 template <int R>
-static int launch_r(const Plan &p, const Step2DArgs &a, int nblocks)
+static int launch_r(const Plan &p, const Step2DArgs &a, int nblocks, hipStream_t stream)
 {
-    if (p.tile_tz == 64) return launch_rt<R, 16, 64>(p, a, nblocks);
-    return launch_rt<R, 32, 32>(p, a, nblocks);
+    if (p.tile_tz == 64) return launch_rt<R, 16, 64>(p, a, nblocks, stream);
+    return launch_rt<R, 32, 32>(p, a, nblocks, stream);
 }
 
-int launch_step2d(const Plan &p, const Step2DArgs &a)
+int launch_step2d(const Plan &p, const Step2DArgs &a, hipStream_t stream)
 {
     const int nblocks = a.ntx * a.ntz * a.nshots + (a.pt_idx ? ((a.itp_npoint + 255) / 256) * a.nshots : 0);
+    if (a.slot_count && 4 * 256 < p.tile_tx * p.tile_tz) return MIFWI_EINVAL;
     switch (p.L.R) {
-        case 1: return launch_r<1>(p, a, nblocks);
-        case 2: return launch_r<2>(p, a, nblocks);
-        case 3: return launch_r<3>(p, a, nblocks);
-        case 4: return launch_r<4>(p, a, nblocks);
-        case 5: return launch_r<5>(p, a, nblocks);
-        case 6: return launch_r<6>(p, a, nblocks);
-        case 7: return launch_r<7>(p, a, nblocks);
-        case 8: return launch_r<8>(p, a, nblocks);
+        case 1: return launch_r<1>(p, a, nblocks, stream);
+        case 2: return launch_r<2>(p, a, nblocks, stream);
+        case 3: return launch_r<3>(p, a, nblocks, stream);
+        case 4: return launch_r<4>(p, a, nblocks, stream);
+        case 5: return launch_r<5>(p, a, nblocks, stream);
+        case 6: return launch_r<6>(p, a, nblocks, stream);
+        case 7: return launch_r<7>(p, a, nblocks, stream);
+        case 8: return launch_r<8>(p, a, nblocks, stream);
     }
     set_error("unsupported stencil radius");
     return MIFWI_EINVAL;

@@ -2,6 +2,7 @@
 // management, sparse geometry tables and the time loops that drive the HIP kernels.
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 
@@ -120,9 +121,17 @@ static void free_sparse(SparseSet &s)
     dev_free(s.uc_count);
     dev_free(s.e_point);
     dev_free(s.e_w);
-    dev_free(s.tile_ptr);
-    dev_free(s.tile_cells);
+    dev_free(s.slot_count);
+    dev_free(s.slot_local);
+    dev_free(s.slot_ep);
+    dev_free(s.slot_ew);
     s = SparseSet{};
+}
+
+static void clear_graphs(Plan &p)
+{
+    for (auto &kv : p.graphs) (void)hipGraphExecDestroy(kv.second.first);
+    p.graphs.clear();
 }
 
 static void destroy(Plan *p)
@@ -130,6 +139,7 @@ static void destroy(Plan *p)
     if (!p) return;
     (void)hipSetDevice(p->device);
     if (p->stream) (void)hipStreamSynchronize(p->stream);
+    clear_graphs(*p);
     dev_free(p->m);
     dev_free(p->eta);
     dev_free(p->rot_u);
@@ -201,7 +211,9 @@ static int build_sparse(Plan &p, SparseSet &S, const T *coords /* [tables][npoin
     std::vector<T> e_w((size_t)tables * S.kmax, T(0));
     const int ntiles = p.kind == 1 ? p.ntx * p.ntz : 0;
     S.ntiles = ntiles;
-    std::vector<int32_t> tile_ptr((size_t)tables * (ntiles + 1), 0), tile_cells((size_t)tables * S.kmax, 0);
+    // per table and tile: (tile-local cell, [(point, weight)...]) lists, flattened after the loop
+    std::vector<std::vector<std::vector<std::pair<int32_t, std::vector<std::pair<int32_t, T>>>>>> tiles(
+        ntiles ? tables : 0);
     struct Entry {
         int32_t cell;
         int32_t point;
@@ -263,29 +275,43 @@ static int build_sparse(Plan &p, SparseSet &S, const T *coords /* [tables][npoin
         uc_count[t] = nu;
         S.max_count = std::max(S.max_count, nu);
         if (ntiles) {
-            // group the unique cells by owning tile (stable: ascending cell order inside a tile)
-            std::vector<std::pair<int32_t, int32_t>> owner(nu);
+            auto &tt = tiles[t];
+            tt.resize(ntiles);
             for (int u = 0; u < nu; ++u) {
                 const long rel = (long)cellp[u] - L.off0;
                 const int i1 = (int)(rel / L.s1), i2 = (int)(rel % L.s1);
-                owner[u] = {(i1 / p.tile_tx) * p.ntz + (i2 / p.tile_tz), u};
+                const int tile = (i1 / p.tile_tx) * p.ntz + (i2 / p.tile_tz);
+                const int local = (i1 % p.tile_tx) * p.tile_tz + (i2 % p.tile_tz);
+                std::vector<std::pair<int32_t, T>> es;
+                for (int e = ptrp[u]; e < ptrp[u + 1]; ++e) es.push_back({ent[e].point, ent[e].w});
+                S.maxe = std::max(S.maxe, (int)es.size());
+                tt[tile].push_back({local, std::move(es)});
+                S.cap = std::max(S.cap, (int)tt[tile].size());
             }
-            std::stable_sort(owner.begin(), owner.end(),
-                             [](const std::pair<int32_t, int32_t> &a, const std::pair<int32_t, int32_t> &b) {
-                                 return a.first < b.first;
-                             });
-            int32_t *tp = &tile_ptr[(size_t)t * (ntiles + 1)];
-            int32_t *tc = &tile_cells[(size_t)t * S.kmax];
-            int u = 0;
+        }
+    }
+    std::vector<int32_t> slot_count, slot_local, slot_ep;
+    std::vector<T> slot_ew;
+    if (ntiles) {
+        S.cap = std::max(S.cap, 1);
+        S.maxe = std::max(S.maxe, 1);
+        slot_count.assign((size_t)tables * ntiles, 0);
+        slot_local.assign((size_t)tables * ntiles * S.cap, -1);
+        slot_ep.assign((size_t)tables * ntiles * S.cap * S.maxe, 0);
+        slot_ew.assign((size_t)tables * ntiles * S.cap * S.maxe, T(0));
+        for (int t = 0; t < tables; ++t)
             for (int tl = 0; tl < ntiles; ++tl) {
-                tp[tl] = u;
-                while (u < nu && owner[u].first == tl) {
-                    tc[u] = owner[u].second;
-                    ++u;
+                const auto &cells = tiles[t][tl];
+                slot_count[(size_t)t * ntiles + tl] = (int32_t)cells.size();
+                for (size_t c = 0; c < cells.size(); ++c) {
+                    const size_t sl = ((size_t)t * ntiles + tl) * S.cap + c;
+                    slot_local[sl] = cells[c].first;
+                    for (size_t e = 0; e < cells[c].second.size(); ++e) {
+                        slot_ep[sl * S.maxe + e] = cells[c].second[e].first;
+                        slot_ew[sl * S.maxe + e] = cells[c].second[e].second;
+                    }
                 }
             }
-            tp[ntiles] = nu;
-        }
     }
     int rc;
     auto up = [&](void **dst, const void *src, size_t bytes) -> int {
@@ -301,8 +327,10 @@ static int build_sparse(Plan &p, SparseSet &S, const T *coords /* [tables][npoin
     if ((rc = up((void **)&S.e_point, e_point.data(), e_point.size() * 4))) return rc;
     if ((rc = up(&S.e_w, e_w.data(), e_w.size() * sizeof(T)))) return rc;
     if (ntiles) {
-        if ((rc = up((void **)&S.tile_ptr, tile_ptr.data(), tile_ptr.size() * 4))) return rc;
-        if ((rc = up((void **)&S.tile_cells, tile_cells.data(), tile_cells.size() * 4))) return rc;
+        if ((rc = up((void **)&S.slot_count, slot_count.data(), slot_count.size() * 4))) return rc;
+        if ((rc = up((void **)&S.slot_local, slot_local.data(), slot_local.size() * 4))) return rc;
+        if ((rc = up((void **)&S.slot_ep, slot_ep.data(), slot_ep.size() * 4))) return rc;
+        if ((rc = up(&S.slot_ew, slot_ew.data(), slot_ew.size() * sizeof(T)))) return rc;
     }
     // the host vectors die at return: make sure the uploads have been consumed
     MIFWI_HIP(hipStreamSynchronize(p.stream));
@@ -422,6 +450,7 @@ static int set_geometry(Plan &p, int nshots, const void *src_coords, const void 
     if (!sc.empty()) MIFWI_HIP(hipMemcpy(sc.data(), src_coords, sc.size() * sizeof(T), hipMemcpyDefault));
     if (!rc_.empty()) MIFWI_HIP(hipMemcpy(rc_.data(), rec_coords, rc_.size() * sizeof(T), hipMemcpyDefault));
     int rc;
+    clear_graphs(p);  // captured loops hold pointers into the geometry tables
     if ((rc = build_sparse<T>(p, p.src, sc.data(), p.cfg.nsrc, nshots, 1))) return rc;
     if ((rc = build_sparse<T>(p, p.rec, rc_.data(), p.cfg.nrec, rec_per_shot ? nshots : 1, rec_per_shot ? 1 : 0)))
         return rc;
@@ -501,13 +530,12 @@ static Step2DArgs base2d(const Plan &p, int nshots)
 static void set_inject(Step2DArgs &a, const SparseSet &S, const void *vals)
 {
     if (S.npoint <= 0 || S.max_count <= 0) return;
-    a.uc_cell = S.uc_cell;
-    a.uc_ptr = S.uc_ptr;
-    a.e_point = S.e_point;
-    a.e_w = (const float *)S.e_w;
-    a.tile_ptr = S.tile_ptr;
-    a.tile_cells = S.tile_cells;
-    a.inj_kmax = S.kmax;
+    a.slot_count = S.slot_count;
+    a.slot_local = S.slot_local;
+    a.slot_ep = S.slot_ep;
+    a.slot_ew = (const float *)S.slot_ew;
+    a.inj_cap = S.cap;
+    a.inj_maxe = S.maxe;
     a.inj_npoint = S.npoint;
     a.inj_per_shot = S.per_shot;
     a.vals_inj = (const float *)vals;
@@ -520,6 +548,58 @@ static void set_interp(Step2DArgs &a, const SparseSet &S, void *vals_out)
     a.itp_npoint = S.npoint;
     a.itp_per_shot = S.per_shot;
     a.vals_out = (float *)vals_out;
+}
+
+// Run one time loop (`enqueue` launches its kernels on p.stream and counts them) bracketed by the
+// plan's events.  Unless MIFWI_FLAG_NO_GRAPH is set the loop is captured once into a HIP graph,
+// keyed by everything that changes its launches, and replayed afterwards: the host then issues one
+// graph launch instead of nt-2 kernel launches, which is what keeps small 2-D grids from being
+// bound by the host's launch rate.
+template <typename F>
+static int run_group(Plan &p, std::tuple<int, int, int, int, int> key, hipStream_t st, int shot0, int nsh, F &&enqueue,
+                     int &launches)
+{
+    int rc = MIFWI_OK;
+    launches = 0;
+    if (p.cfg.flags & MIFWI_FLAG_NO_GRAPH) return enqueue(st, shot0, nsh, launches);
+    auto it = p.graphs.find(key);
+    if (it == p.graphs.end()) {
+        hipGraph_t graph = nullptr;
+        MIFWI_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+        rc = enqueue(st, shot0, nsh, launches);
+        hipError_t e = hipStreamEndCapture(st, &graph);
+        if (rc) {
+            if (graph) (void)hipGraphDestroy(graph);
+            return rc;
+        }
+        if (e != hipSuccess) return fail(MIFWI_EHIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
+        hipGraphExec_t exec = nullptr;
+        e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(graph);
+        if (e != hipSuccess) return fail(MIFWI_EHIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(e));
+        it = p.graphs.emplace(key, std::make_pair(exec, launches)).first;
+    }
+    launches = it->second.second;
+    MIFWI_HIP(hipGraphLaunch(it->second.first, st));
+    return MIFWI_OK;
+}
+
+// `enqueue(stream, shot0, nsh, launches)` launches the loop for shots shot0..shot0+nsh-1.
+// (Splitting the batch into shot groups on separate streams was measured and rejected: chains on
+// different hardware queues did not overlap on MI355X, 8 shots in 2/4/8 groups ran 1.2-3x slower
+// than one chain.)
+template <typename F>
+static int timed_loop(Plan &p, std::tuple<int, int, int, int> key, int nshots, F &&enqueue, int &launches, float &ms)
+{
+    int rc = MIFWI_OK;
+    launches = 0;
+    MIFWI_HIP(hipEventRecord(p.ev0, p.stream));
+    auto k5 = std::make_tuple(std::get<0>(key), std::get<1>(key), std::get<2>(key), std::get<3>(key), 0);
+    if ((rc = run_group(p, k5, p.stream, 0, nshots, enqueue, launches))) return rc;
+    MIFWI_HIP(hipEventRecord(p.ev1, p.stream));
+    MIFWI_HIP(hipEventSynchronize(p.ev1));
+    MIFWI_HIP(hipEventElapsedTime(&ms, p.ev0, p.ev1));
+    return MIFWI_OK;
 }
 
 // forward time loop on data already resident on the device (d_wavelet -> d_rec)
@@ -550,10 +630,10 @@ static int run_forward(Plan &p, int nshots, int save)
     MIFWI_HIP(hipMemsetAsync(p.d_rec, 0, (size_t)nshots * nt * p.cfg.nrec * sizeof(T), p.stream));
     const StepConsts<T> k = make_consts<T>(p);
     auto lvl = [&](int t) { return base + (long)(save ? t : t % 3) * L.field; };
-    MIFWI_HIP(hipEventRecord(p.ev0, p.stream));
-    int launches = 0;
+    auto enqueue = [&](hipStream_t st, int shot0, int nsh, int &launches) -> int {
     if (p.kind == 1) {
-        Step2DArgs a = base2d(p, nshots);
+        Step2DArgs a = base2d(p, nsh);
+        a.shot0 = shot0;
         a.shot_stride = shot_stride;
         set_inject(a, p.src, p.d_wavelet);
         set_interp(a, p.rec, p.d_rec);
@@ -562,7 +642,7 @@ static int run_forward(Plan &p, int nshots, int save)
             a.old = (const float *)lvl(time - 1);
             a.out = (float *)lvl(time + 1);
             a.time = time;
-            if ((rc = launch_step2d(p, a))) return rc;
+            if ((rc = launch_step2d(p, a, st))) return rc;
             ++launches;
         }
     }
@@ -585,10 +665,11 @@ static int run_forward(Plan &p, int nshots, int save)
         if ((rc = launch_sparse<T>(p, q, nshots))) return rc;
         launches += 2;
     }
-    MIFWI_HIP(hipEventRecord(p.ev1, p.stream));
-    MIFWI_HIP(hipEventSynchronize(p.ev1));
+    return MIFWI_OK;
+    };
+    int launches = 0;
     float ms = 0;
-    MIFWI_HIP(hipEventElapsedTime(&ms, p.ev0, p.ev1));
+    if ((rc = timed_loop(p, std::make_tuple(0, nshots, save ? 1 : 0, 0), nshots, enqueue, launches, ms))) return rc;
     fill_stats(p, ms, nt - 2, nshots, 20.0, launches, false);
     if (save) {
         p.saved_valid = true;
@@ -628,10 +709,10 @@ static int run_backward(Plan &p, int nshots, bool with_grad, bool with_illum)
     auto lvl = [&](int t) { return base + (long)((t + 3) % 3) * L.field; };
     const T *sv = (const T *)p.saved;
     const long sv_stride = (long)nt * L.field;
-    MIFWI_HIP(hipEventRecord(p.ev0, p.stream));
-    int launches = 0;
+    auto enqueue = [&](hipStream_t st, int shot0, int nsh, int &launches) -> int {
     if (p.kind == 1) {
-        Step2DArgs a = base2d(p, nshots);
+        Step2DArgs a = base2d(p, nsh);
+        a.shot0 = shot0;
         a.shot_stride = shot_stride;
         set_inject(a, p.rec, p.d_res);
         if (!with_grad) set_interp(a, p.src, p.d_srca);
@@ -650,7 +731,7 @@ static int run_backward(Plan &p, int nshots, bool with_grad, bool with_illum)
                 a.g_shot_stride = L.field;
                 a.first = (time == nt - 2);
             }
-            if ((rc = launch_step2d(p, a))) return rc;
+            if ((rc = launch_step2d(p, a, st))) return rc;
             ++launches;
         }
     }
@@ -685,10 +766,12 @@ static int run_backward(Plan &p, int nshots, bool with_grad, bool with_illum)
         if ((rc = launch_sparse<T>(p, q, nshots))) return rc;
         launches += 2;
     }
-    MIFWI_HIP(hipEventRecord(p.ev1, p.stream));
-    MIFWI_HIP(hipEventSynchronize(p.ev1));
+    return MIFWI_OK;
+    };
+    int launches = 0;
     float ms = 0;
-    MIFWI_HIP(hipEventElapsedTime(&ms, p.ev0, p.ev1));
+    if ((rc = timed_loop(p, std::make_tuple(1, nshots, with_grad ? 1 : 0, with_illum ? 1 : 0), nshots, enqueue, launches, ms)))
+        return rc;
     fill_stats(p, ms, nt - 2, nshots, with_grad ? 32.0 : 20.0, launches, true);
     p.rot_v_valid = true;
     return MIFWI_OK;

@@ -5,7 +5,9 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <map>
 #include <string>
+#include <tuple>
 #include <vector>
 
 #include "mifwi.h"
@@ -69,10 +71,15 @@ struct SparseSet {
     int32_t *e_point = nullptr;  // [tables][kmax]
     void *e_w = nullptr;         // [tables][kmax] (T)
     int max_count = 0;           // max unique cells over tables (host copy)
-    // unique cells grouped by the tile (of the tiled kernels) that owns them
+    // Injection view of the tiled kernels: per tile a fixed-capacity table of the cells it owns, so
+    // that a block finds its work with loads whose addresses depend on nothing but its tile id.
     int ntiles = 0;
-    int32_t *tile_ptr = nullptr;   // [tables][ntiles+1] ranges into tile_cells
-    int32_t *tile_cells = nullptr; // [tables][kmax] indices into uc_cell / uc_ptr
+    int cap = 0;                   // slots per tile (max cells owned by any tile)
+    int maxe = 0;                  // entries per slot (max points touching one cell)
+    int32_t *slot_count = nullptr; // [tables][ntiles] cells owned by the tile
+    int32_t *slot_local = nullptr; // [tables][ntiles][cap] tile-local cell index, -1 = empty
+    int32_t *slot_ep = nullptr;    // [tables][ntiles][cap][maxe] point index (0 when padding)
+    void *slot_ew = nullptr;       // [tables][ntiles][cap][maxe] weight (0 when padding)
 };
 
 struct Plan {
@@ -111,6 +118,9 @@ struct Plan {
     // tiled fast path (2-D float32): tile shape and count; kind 0 = generic kernels only
     int kind = 0;
     int tile_tx = 0, tile_tz = 0, ntx = 0, ntz = 0;
+
+    // captured time loops: (loop kind, nshots, variant a, variant b, group) -> executable graph + launches
+    std::map<std::tuple<int, int, int, int, int>, std::pair<hipGraphExec_t, int>> graphs;
 
     mifwi_stats stats{};
     int64_t device_bytes = 0;
@@ -198,18 +208,18 @@ struct Step2DArgs {
     float dt, dt2, inv_dt2;
     int n1, n2;
     long s1, off0;
-    int ntx, ntz, nshots;
+    int ntx, ntz;
+    int nshots, shot0;  // this launch covers shots shot0 .. shot0+nshots-1 (all pointers are shot 0's)
     // gradient (um == nullptr: plain propagation)
     const float *um, *uc, *up;
     long u_shot_stride;
     float *grad, *illum;
     long g_shot_stride;
     int first;
-    // injection (tile_ptr == nullptr: none)
-    const int32_t *uc_cell, *uc_ptr, *e_point;
-    const float *e_w;
-    const int32_t *tile_ptr, *tile_cells;
-    int inj_kmax, inj_npoint, inj_per_shot;
+    // injection (slot_count == nullptr: none)
+    const int32_t *slot_count, *slot_local, *slot_ep;
+    const float *slot_ew;
+    int inj_cap, inj_maxe, inj_npoint, inj_per_shot;
     const float *vals_inj;
     // interpolation of `cur` (pt_idx == nullptr: none)
     const int32_t *pt_idx;
@@ -218,6 +228,6 @@ struct Step2DArgs {
     float *vals_out;
     int time, nt;
 };
-int launch_step2d(const Plan &p, const Step2DArgs &a);
+int launch_step2d(const Plan &p, const Step2DArgs &a, hipStream_t stream);
 
 }  // namespace mifwi
