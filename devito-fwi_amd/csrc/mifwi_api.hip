@@ -125,6 +125,9 @@ static void free_sparse(SparseSet &s)
     dev_free(s.slot_local);
     dev_free(s.slot_ep);
     dev_free(s.slot_ew);
+    dev_free(s.cell_ptr);
+    dev_free(s.cell_local);
+    dev_free(s.cell_uc);
     s = SparseSet{};
 }
 
@@ -211,6 +214,12 @@ static int build_sparse(Plan &p, SparseSet &S, const T *coords /* [tables][npoin
     std::vector<T> e_w((size_t)tables * S.kmax, T(0));
     const int ntiles = p.kind == 1 ? p.ntx * p.ntz : 0;
     S.ntiles = ntiles;
+    const int ntiles3 = p.kind == 2 ? p.ntx * p.ntz : 0;
+    std::vector<int32_t> cell_ptr((size_t)tables * ntiles3 * (L.n[0] + 1), 0), cell_local, cell_uc;
+    if (ntiles3) {
+        cell_local.assign((size_t)tables * S.kmax, 0);
+        cell_uc.assign((size_t)tables * S.kmax, 0);
+    }
     // per table and tile: (tile-local cell, [(point, weight)...]) lists, flattened after the loop
     std::vector<std::vector<std::vector<std::pair<int32_t, std::vector<std::pair<int32_t, T>>>>>> tiles(
         ntiles ? tables : 0);
@@ -274,6 +283,36 @@ static int build_sparse(Plan &p, SparseSet &S, const T *coords /* [tables][npoin
         ptrp[nu] = (int32_t)ent.size();
         uc_count[t] = nu;
         S.max_count = std::max(S.max_count, nu);
+        if (ntiles3) {
+            // order the owned cells by ((y,z) tile, x plane, position in the tile)
+            struct C3 {
+                int32_t tile, x, local, u;
+            };
+            std::vector<C3> cs(nu);
+            for (int u = 0; u < nu; ++u) {
+                const long rel = (long)cellp[u] - L.off0;
+                const int i0 = (int)(rel / L.s0);
+                const long r1 = rel - (long)i0 * L.s0;
+                const int i1 = (int)(r1 / L.s1), i2 = (int)(r1 % L.s1);
+                cs[u] = C3{(i1 / p.tile_tx) * p.ntz + (i2 / p.tile_tz), i0, (i1 % p.tile_tx) * p.tile_tz + (i2 % p.tile_tz), u};
+            }
+            std::sort(cs.begin(), cs.end(), [](const C3 &a, const C3 &b) {
+                if (a.tile != b.tile) return a.tile < b.tile;
+                if (a.x != b.x) return a.x < b.x;
+                return a.local < b.local;
+            });
+            int32_t *cp = &cell_ptr[(size_t)t * ntiles3 * (L.n[0] + 1)];
+            int j = 0;
+            for (int tl = 0; tl < ntiles3; ++tl)
+                for (int x = 0; x <= L.n[0]; ++x) {
+                    cp[(size_t)tl * (L.n[0] + 1) + x] = j;
+                    while (x < L.n[0] && j < nu && cs[j].tile == tl && cs[j].x == x) {
+                        cell_local[(size_t)t * S.kmax + j] = cs[j].local;
+                        cell_uc[(size_t)t * S.kmax + j] = cs[j].u;
+                        ++j;
+                    }
+                }
+        }
         if (ntiles) {
             auto &tt = tiles[t];
             tt.resize(ntiles);
@@ -326,6 +365,11 @@ static int build_sparse(Plan &p, SparseSet &S, const T *coords /* [tables][npoin
     if ((rc = up((void **)&S.uc_count, uc_count.data(), uc_count.size() * 4))) return rc;
     if ((rc = up((void **)&S.e_point, e_point.data(), e_point.size() * 4))) return rc;
     if ((rc = up(&S.e_w, e_w.data(), e_w.size() * sizeof(T)))) return rc;
+    if (ntiles3) {
+        if ((rc = up((void **)&S.cell_ptr, cell_ptr.data(), cell_ptr.size() * 4))) return rc;
+        if ((rc = up((void **)&S.cell_local, cell_local.data(), cell_local.size() * 4))) return rc;
+        if ((rc = up((void **)&S.cell_uc, cell_uc.data(), cell_uc.size() * 4))) return rc;
+    }
     if (ntiles) {
         if ((rc = up((void **)&S.slot_count, slot_count.data(), slot_count.size() * 4))) return rc;
         if ((rc = up((void **)&S.slot_local, slot_local.data(), slot_local.size() * 4))) return rc;
@@ -388,6 +432,19 @@ static int create(const mifwi_config *cfg, mifwi_plan **out)
         else p->tile_tx = 32, p->tile_tz = 32;
         p->ntx = (n1 + p->tile_tx - 1) / p->tile_tx;
         p->ntz = (n2 + p->tile_tz - 1) / p->tile_tz;
+    }
+    if (cfg->ndim == 3 && cfg->dtype == MIFWI_F32 && !(cfg->flags & MIFWI_FLAG_GENERIC)) {
+        // 2.5-D fast path: 16 x 64 tiles of the (y, z) plane, x split into chunks so that one launch
+        // offers several blocks per CU
+        p->kind = 2;
+        p->tile_tx = 16, p->tile_tz = 64;
+        p->ntx = (p->L.n[1] + 15) / 16;
+        p->ntz = (p->L.n[2] + 63) / 64;
+        const int want = (1536 + p->ntx * p->ntz * cfg->max_shots - 1) / (p->ntx * p->ntz * cfg->max_shots);
+        const int min_chunk = std::max(8, 2 * p->L.R);
+        p->nchunk = std::max(1, std::min(want, p->L.n[0] / min_chunk));
+        p->xchunk = (p->L.n[0] + p->nchunk - 1) / p->nchunk;
+        p->nchunk = (p->L.n[0] + p->xchunk - 1) / p->xchunk;
     }
     auto bail = [&](int code) {
         destroy(p);
@@ -550,6 +607,64 @@ static void set_interp(Step2DArgs &a, const SparseSet &S, void *vals_out)
     a.vals_out = (float *)vals_out;
 }
 
+// constants of the 2.5-D kernel
+static Step3DArgs base3d(const Plan &p, int nshots)
+{
+    Step3DArgs a{};
+    double w[kMaxR + 1];
+    fd2_weights(p.L.R, w);
+    double ih[3];
+    for (int d = 0; d < 3; ++d) ih[d] = 1.0 / (p.cfg.spacing[d] * p.cfg.spacing[d]);
+    a.c0 = (float)(w[0] * ih[0] + w[0] * ih[1] + w[0] * ih[2]);
+    for (int j = 0; j <= p.L.R; ++j) {
+        a.cx[j] = (float)(w[j] * ih[0]);
+        a.cy[j] = (float)(w[j] * ih[1]);
+        a.cz[j] = (float)(w[j] * ih[2]);
+    }
+    a.dt = (float)p.cfg.dt;
+    a.dt2 = a.dt * a.dt;
+    a.inv_dt2 = 1.0f / a.dt2;
+    a.n0 = p.L.n[0];
+    a.n1 = p.L.n[1];
+    a.n2 = p.L.n[2];
+    a.s0 = p.L.s0;
+    a.s1 = p.L.s1;
+    a.off0 = p.L.off0;
+    a.nty = p.ntx;
+    a.ntz = p.ntz;
+    a.nchunk = p.nchunk;
+    a.xchunk = p.xchunk;
+    a.nshots = nshots;
+    a.nwork = p.ntx * p.ntz * p.nchunk * nshots;
+    a.m = (const float *)p.m;
+    a.eta = (const float *)p.eta;
+    a.nt = p.cfg.nt;
+    return a;
+}
+static void set_inject3(Step3DArgs &a, const SparseSet &S, const void *vals)
+{
+    if (S.npoint <= 0 || S.max_count <= 0) return;
+    a.cell_ptr = S.cell_ptr;
+    a.cell_local = S.cell_local;
+    a.cell_uc = S.cell_uc;
+    a.uc_ptr = S.uc_ptr;
+    a.e_point = S.e_point;
+    a.e_w = (const float *)S.e_w;
+    a.inj_kmax = S.kmax;
+    a.inj_npoint = S.npoint;
+    a.inj_per_shot = S.per_shot;
+    a.vals_inj = (const float *)vals;
+}
+static void set_interp3(Step3DArgs &a, const SparseSet &S, void *vals_out)
+{
+    if (S.npoint <= 0) return;
+    a.pt_idx = S.pt_idx;
+    a.pt_w = (const float *)S.pt_w;
+    a.itp_npoint = S.npoint;
+    a.itp_per_shot = S.per_shot;
+    a.vals_out = (float *)vals_out;
+}
+
 // Run one time loop (`enqueue` launches its kernels on p.stream and counts them) bracketed by the
 // plan's events.  Unless MIFWI_FLAG_NO_GRAPH is set the loop is captured once into a HIP graph,
 // keyed by everything that changes its launches, and replayed afterwards: the host then issues one
@@ -646,6 +761,20 @@ static int run_forward(Plan &p, int nshots, int save)
             ++launches;
         }
     }
+    if (p.kind == 2) {
+        Step3DArgs a = base3d(p, nsh);
+        a.shot_stride = shot_stride;
+        set_inject3(a, p.src, p.d_wavelet);
+        set_interp3(a, p.rec, p.d_rec);
+        for (int time = 1; time <= nt - 2; ++time) {
+            a.cur = (const float *)lvl(time);
+            a.old = (const float *)lvl(time - 1);
+            a.out = (float *)lvl(time + 1);
+            a.time = time;
+            if ((rc = launch_step3d(p, a, st))) return rc;
+            ++launches;
+        }
+    }
     for (int time = 1; p.kind == 0 && time <= nt - 2; ++time) {
         StepPtrs<T> sp{lvl(time), lvl(time - 1), lvl(time + 1), shot_stride, (const T *)p.m, (const T *)p.eta};
         GradPtrs<T> gp{};
@@ -732,6 +861,30 @@ static int run_backward(Plan &p, int nshots, bool with_grad, bool with_illum)
                 a.first = (time == nt - 2);
             }
             if ((rc = launch_step2d(p, a, st))) return rc;
+            ++launches;
+        }
+    }
+    if (p.kind == 2) {
+        Step3DArgs a = base3d(p, nsh);
+        a.shot_stride = shot_stride;
+        set_inject3(a, p.rec, p.d_res);
+        if (!with_grad) set_interp3(a, p.src, p.d_srca);
+        for (int time = nt - 2; time >= 1; --time) {
+            a.cur = (const float *)lvl(time);
+            a.old = (const float *)lvl(time + 1);
+            a.out = (float *)lvl(time - 1);
+            a.time = time;
+            if (with_grad) {
+                a.um = (const float *)sv + (long)(time - 1) * L.field;
+                a.uc = (const float *)sv + (long)time * L.field;
+                a.up = (const float *)sv + (long)(time + 1) * L.field;
+                a.u_shot_stride = sv_stride;
+                a.grad = (float *)p.d_grad;
+                a.illum = with_illum ? (float *)p.d_illum : nullptr;
+                a.g_shot_stride = L.field;
+                a.first = (time == nt - 2);
+            }
+            if ((rc = launch_step3d(p, a, st))) return rc;
             ++launches;
         }
     }

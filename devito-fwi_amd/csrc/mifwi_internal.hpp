@@ -80,6 +80,10 @@ struct SparseSet {
     int32_t *slot_local = nullptr; // [tables][ntiles][cap] tile-local cell index, -1 = empty
     int32_t *slot_ep = nullptr;    // [tables][ntiles][cap][maxe] point index (0 when padding)
     void *slot_ew = nullptr;       // [tables][ntiles][cap][maxe] weight (0 when padding)
+    // Injection view of the 2.5-D kernel: owned cells ordered by ((y,z) tile, x plane)
+    int32_t *cell_ptr = nullptr;   // [tables][ntiles][n0+1] ranges into cell_local / cell_uc
+    int32_t *cell_local = nullptr; // [tables][kmax] tile-local (y,z) index of the cell
+    int32_t *cell_uc = nullptr;    // [tables][kmax] index of the cell in uc_ptr
 };
 
 struct Plan {
@@ -115,9 +119,12 @@ struct Plan {
     double *d_partial = nullptr;             // misfit partial sums
     double *d_fval = nullptr;                // [max_shots]
 
-    // tiled fast path (2-D float32): tile shape and count; kind 0 = generic kernels only
+    // fast paths (float32): kind 1 = tiled 2-D kernel, tiles tile_tx x tile_tz over (x, z);
+    // kind 2 = 2.5-D kernel, tiles tile_tx x tile_tz over (y, z), marching x in chunks of xchunk
+    // planes; kind 0 = generic kernels only
     int kind = 0;
     int tile_tx = 0, tile_tz = 0, ntx = 0, ntz = 0;
+    int xchunk = 0, nchunk = 0;
 
     // captured time loops: (loop kind, nshots, variant a, variant b, group) -> executable graph + launches
     std::map<std::tuple<int, int, int, int, int>, std::pair<hipGraphExec_t, int>> graphs;
@@ -229,5 +236,36 @@ struct Step2DArgs {
     int time, nt;
 };
 int launch_step2d(const Plan &p, const Step2DArgs &a, hipStream_t stream);
+
+// ---- 2.5-D fast path for 3-D grids (kernels_3d.hip) -------------------------------------------
+struct Step3DArgs {
+    const float *cur, *old;
+    float *out;
+    long shot_stride;
+    const float *m, *eta;
+    float c0, cx[kMaxR + 1], cy[kMaxR + 1], cz[kMaxR + 1];
+    float dt, dt2, inv_dt2;
+    int n0, n1, n2;
+    long s0, s1, off0;
+    int nty, ntz, nchunk, xchunk, nwork, nshots;
+    // gradient (um == nullptr: plain propagation)
+    const float *um, *uc, *up;
+    long u_shot_stride;
+    float *grad, *illum;
+    long g_shot_stride;
+    int first;
+    // injection (cell_ptr == nullptr: none)
+    const int32_t *cell_ptr, *cell_local, *cell_uc, *uc_ptr, *e_point;
+    const float *e_w;
+    int inj_kmax, inj_npoint, inj_per_shot;
+    const float *vals_inj;
+    // interpolation of `cur` (pt_idx == nullptr: none)
+    const int32_t *pt_idx;
+    const float *pt_w;
+    int itp_npoint, itp_per_shot;
+    float *vals_out;
+    int time, nt;
+};
+int launch_step3d(const Plan &p, const Step3DArgs &a, hipStream_t stream);
 
 }  // namespace mifwi

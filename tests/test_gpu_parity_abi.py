@@ -78,9 +78,22 @@ def test_2d_many_tiles_ragged(mifwi, shape):
     _check_case(mifwi, Case(shape, (10.0, 10.0), nbl=9, space_order=8, nt=120, nshots=3, nrec=57, seed=13))
 
 
+@pytest.mark.parametrize("flags", [0, 4])
 @pytest.mark.parametrize("so", [4, 8, 16])
-def test_3d_orders(mifwi, so):
-    _check_case(mifwi, Case((14, 12, 13), (10.0, 10.0, 10.0), nbl=6, space_order=so, nt=70, nshots=2, nrec=9, seed=5))
+def test_3d_orders(mifwi, so, flags):
+    _check_case(mifwi, Case((14, 12, 13), (10.0, 10.0, 10.0), nbl=6, space_order=so, nt=70, nshots=2, nrec=9, seed=5),
+                flags)
+
+
+@pytest.mark.parametrize("so", [2, 6, 10, 12, 14])
+def test_3d_other_orders(mifwi, so):
+    _check_case(mifwi, Case((11, 10, 12), (10.0, 12.0, 9.0), nbl=5, space_order=so, nt=50, nshots=1, nrec=6, seed=6))
+
+
+@pytest.mark.parametrize("shape", [(40, 20, 70), (21, 37, 13)])
+def test_3d_many_tiles_chunks_ragged(mifwi, shape):
+    # several (y,z) tiles, several x chunks, z widths that are not multiples of 4, dense receivers
+    _check_case(mifwi, Case(shape, (10.0, 10.0, 10.0), nbl=6, space_order=8, nt=60, nshots=2, nrec=80, seed=17))
 
 
 def test_1d(mifwi):
