@@ -26,32 +26,90 @@ __device__ inline float fast_div3(float a, float b)
     return a * r;
 }
 
-__device__ inline float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
+// V consecutive floats (V = 2 or 4) moved with one aligned 8- or 16-byte access.
+// Addresses are a uniform (SGPR) base pointer plus a 32-bit per-lane byte offset, the cheapest
+// global addressing mode; one field level stays below 4 GB (checked when the plan is created).
+typedef float vf2 __attribute__((ext_vector_type(2)));
+typedef float vf4 __attribute__((ext_vector_type(4)));
+template <int V>
+struct VecT;
+template <>
+struct VecT<2> {
+    typedef vf2 type;
+};
+template <>
+struct VecT<4> {
+    typedef vf4 type;
+};
 
-template <int R, int TY, int TZ, bool GRAD>
-__global__ __launch_bounds__(256) void step3d_kernel(Step3DArgs a)
+template <int V>
+__device__ inline void ldv(const char *base, unsigned off, float (&d)[V])
 {
+    const typename VecT<V>::type v = *reinterpret_cast<const typename VecT<V>::type *>(base + off);
+#pragma unroll
+    for (int i = 0; i < V; ++i) d[i] = v[i];
+}
+// streaming accesses (each byte used once per step) are non-temporal so that they do not evict the
+// planes of the stencilled field that neighbouring tiles re-read from L2
+template <int V>
+__device__ inline void ldv_stream(const char *base, unsigned off, float (&d)[V])
+{
+    const typename VecT<V>::type v =
+        __builtin_nontemporal_load(reinterpret_cast<const typename VecT<V>::type *>(base + off));
+#pragma unroll
+    for (int i = 0; i < V; ++i) d[i] = v[i];
+}
+template <int V>
+__device__ inline void stv_stream(char *base, unsigned off, const float (&d)[V])
+{
+    typename VecT<V>::type v;
+#pragma unroll
+    for (int i = 0; i < V; ++i) v[i] = d[i];
+    __builtin_nontemporal_store(v, reinterpret_cast<typename VecT<V>::type *>(base + off));
+}
+template <int V>
+__device__ inline void lds_ldv(const float *p, float (&d)[V])
+{
+    const typename VecT<V>::type v = *reinterpret_cast<const typename VecT<V>::type *>(p);
+#pragma unroll
+    for (int i = 0; i < V; ++i) d[i] = v[i];
+}
+template <int V>
+__device__ inline void lds_stv(float *p, const float (&d)[V])
+{
+    typename VecT<V>::type v;
+#pragma unroll
+    for (int i = 0; i < V; ++i) v[i] = d[i];
+    *reinterpret_cast<typename VecT<V>::type *>(p) = v;
+}
+
+// R: stencil radius.  TY x TZ: tile of the (y, z) plane.  V: points per thread (TY*TZ/V threads).
+// GRAD: also accumulate the FWI gradient.  ISO: equal spacing in x, y and z (one coefficient set).
+template <int R, int TY, int TZ, int V, bool GRAD, bool ISO>
+__global__ __launch_bounds__(TY *TZ / V) void step3d_kernel(Step3DArgs a)
+{
+    constexpr int NT = TY * TZ / V;                     // threads per block
     constexpr int RZ = (R + 3) / 4 * 4;
     constexpr int RZ4 = RZ / 4;
     constexpr int ROWF4 = (TZ + 2 * RZ) / 4;
     constexpr int P = tile2d_lds_pitch(TZ, R);
-    constexpr int TQ = TZ / 4;
+    constexpr int TQ = TZ / V;                          // threads per tile row
     constexpr int NBAND = R * ROWF4;                    // float4 in the top (or bottom) halo band
     constexpr int NH = 2 * NBAND + 2 * TY * RZ4;        // float4 in the halo ring
-    constexpr int NHT = (NH + 255) / 256;               // ring float4 per thread
-    static_assert(TQ * TY == 256, "one float4 per thread and plane");
+    constexpr int NHT = (NH + NT - 1) / NT;             // ring float4 per thread
     __shared__ __attribute__((aligned(16))) float lds[2][(TY + 2 * R) * P];
     __shared__ __attribute__((aligned(16))) float acc[TY * TZ];
 
     const int tid = threadIdx.x;
     // interpolation blocks come first; their count is padded to a multiple of 8 so that the tile
     // blocks keep id % 8 == XCD label
-    const int nitp_blocks = a.pt_idx ? (((a.itp_npoint + 255) / 256) * a.nshots + 7) / 8 * 8 : 0;
+    const int nitp_real = a.pt_idx ? ((a.itp_npoint + NT - 1) / NT) * a.nshots : 0;
+    const int nitp_blocks = (nitp_real + 7) / 8 * 8;
     int bid = blockIdx.x;
     if (bid < nitp_blocks) {
         const int shot = bid % a.nshots;
-        const int pnt = (bid / a.nshots) * 256 + tid;
-        if (pnt >= a.itp_npoint || bid >= ((a.itp_npoint + 255) / 256) * a.nshots) return;
+        const int pnt = (bid / a.nshots) * NT + tid;
+        if (pnt >= a.itp_npoint || bid >= nitp_real) return;
         const int tab = a.itp_per_shot ? shot : 0;
         const int32_t *idx = a.pt_idx + ((long)tab * a.itp_npoint + pnt) * 8;
         const float *w = a.pt_w + ((long)tab * a.itp_npoint + pnt) * 8;
@@ -80,21 +138,25 @@ __global__ __launch_bounds__(256) void step3d_kernel(Step3DArgs a)
     const int y0 = tile_y * TY, z0 = tile_z * TZ;
 
     const int ty = tid / TQ, tq = tid - ty * TQ;
-    const int y = y0 + ty, z = z0 + 4 * tq;
+    const int y = y0 + ty, z = z0 + V * tq;
     const bool live = (y < a.n1) && (z < a.n2);
-    const bool full = (z + 3 < a.n2);
-    const long col = a.off0 + (long)y * a.s1 + z;                 // own column, plane 0
-    const float *cur = a.cur + (long)shot * a.shot_stride;
-    const float *old = a.old + (long)shot * a.shot_stride;
-    float *out = a.out + (long)shot * a.shot_stride;
+    const bool full = (z + V - 1 < a.n2);
+    // own column: byte offset of (plane 0, y, z) from a level base; planes advance by sb bytes
+    const unsigned col = (unsigned)((a.off0 + (long)y * a.s1 + z) * 4);
+    const long sb = a.s0 * 4;
+    const char *cur = reinterpret_cast<const char *>(a.cur + (long)shot * a.shot_stride);
+    const char *old = reinterpret_cast<const char *>(a.old + (long)shot * a.shot_stride);
+    char *out = reinterpret_cast<char *>(a.out + (long)shot * a.shot_stride);
+    const char *mb = reinterpret_cast<const char *>(a.m);
+    const char *eb = reinterpret_cast<const char *>(a.eta);
 
-    // halo-ring pieces of this thread: LDS offset and offset from the plane's tile origin
+    // halo-ring pieces (float4) of this thread: LDS offset and byte offset from a plane base
     int h_lds[NHT];
-    long h_glb[NHT];
+    unsigned h_glb[NHT];
     bool h_ok[NHT];
 #pragma unroll
     for (int i = 0; i < NHT; ++i) {
-        const int h = tid + i * 256;
+        const int h = tid + i * NT;
         int row, c4;
         if (h < 2 * NBAND) {
             const int band = h / NBAND, r = (h - band * NBAND) / ROWF4;
@@ -104,12 +166,12 @@ __global__ __launch_bounds__(256) void step3d_kernel(Step3DArgs a)
             const int hh = h - 2 * NBAND;
             const int r = hh / (2 * RZ4), cc = hh - r * (2 * RZ4);
             row = R + r;
-            c4 = cc < RZ4 ? cc : (TQ + cc);
+            c4 = cc < RZ4 ? cc : (TZ / 4 + cc);
         }
         const int gy = y0 - R + row;
         h_ok[i] = (h < NH) && (gy < a.n1 + R);
         h_lds[i] = row * P + 4 * c4;
-        h_glb[i] = a.off0 + (long)gy * a.s1 + (z0 - RZ + 4 * c4);
+        h_glb[i] = (unsigned)((a.off0 + (long)gy * a.s1 + (z0 - RZ + 4 * c4)) * 4);
     }
 
     // injection work of this block: CSR over (tile, plane), ranges for the whole chunk
@@ -117,35 +179,51 @@ __global__ __launch_bounds__(256) void step3d_kernel(Step3DArgs a)
     const int32_t *cptr = a.cell_ptr ? a.cell_ptr + ((long)inj_tab * a.nty * a.ntz + tile) * (a.n0 + 1) : nullptr;
     const bool any_inj = cptr ? (cptr[xa] < cptr[xb]) : false;   // block-uniform
 
-    // register queue: planes i-R .. i+R of the own column; prime it for i = xa
-    float4 q[2 * R + 1];
+    // register queue: planes x-R .. x+R of the own column, plus plane x+R+1 in flight (qn)
+    float q[2 * R + 1][V], qn[V];
 #pragma unroll
-    for (int j = 0; j < 2 * R; ++j)
-        q[j + 1] = live ? ld4(cur + col + (long)(xa - R + j) * a.s0) : make_float4(0.f, 0.f, 0.f, 0.f);
-    float4 hv[NHT];
+    for (int j = 0; j < 2 * R; ++j) {
 #pragma unroll
-    for (int i = 0; i < NHT; ++i)
-        hv[i] = h_ok[i] ? ld4(cur + h_glb[i] + (long)xa * a.s0) : make_float4(0.f, 0.f, 0.f, 0.f);
-    float4 m4 = make_float4(1.f, 1.f, 1.f, 1.f), e4 = make_float4(0.f, 0.f, 0.f, 0.f), o4 = e4;
-    if (live) {
-        m4 = ld4(a.m + col + (long)xa * a.s0);
-        e4 = ld4(a.eta + col + (long)xa * a.s0);
-        o4 = ld4(old + col + (long)xa * a.s0);
+        for (int i = 0; i < V; ++i) q[j + 1][i] = 0.f;
+        if (live) ldv<V>(cur + (long)(xa - R + j) * sb, col, q[j + 1]);
+    }
+#pragma unroll
+    for (int i = 0; i < V; ++i) qn[i] = 0.f;
+    if (live) ldv<V>(cur + (long)(xa + R) * sb, col, qn);
+    float hv[NHT][4];
+#pragma unroll
+    for (int i = 0; i < NHT; ++i) {
+        hv[i][0] = hv[i][1] = hv[i][2] = hv[i][3] = 0.f;
+        if (h_ok[i]) ldv<4>(cur + (long)xa * sb, h_glb[i], hv[i]);
     }
 
     int buf = 0;
     for (int x = xa; x < xb; ++x) {
-        // shift the queue and fetch plane x+R of the own column
+        // advance the queue: plane x+R arrived during the previous plane, x+R+1 is requested now
 #pragma unroll
-        for (int j = 0; j < 2 * R; ++j) q[j] = q[j + 1];
-        q[2 * R] = live ? ld4(cur + col + (long)(x + R) * a.s0) : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int j = 0; j < 2 * R; ++j) {
+#pragma unroll
+            for (int i = 0; i < V; ++i) q[j][i] = q[j + 1][i];
+        }
+#pragma unroll
+        for (int i = 0; i < V; ++i) q[2 * R][i] = qn[i];
+        if (live && x + 1 < xb) ldv<V>(cur + (long)(x + R + 1) * sb, col, qn);
+        // this plane's coefficients are only needed once the stencil sum is complete
+        float mm[V], ee[V], oo[V];
+#pragma unroll
+        for (int i = 0; i < V; ++i) mm[i] = 1.f, ee[i] = 0.f, oo[i] = 0.f;
+        if (live) {
+            ldv_stream<V>(mb + (long)x * sb, col, mm);
+            ldv_stream<V>(eb + (long)x * sb, col, ee);
+            ldv_stream<V>(old + (long)x * sb, col, oo);
+        }
 
         // stage plane x: centre from the queue, ring from the registers loaded one plane ago
         float *L = lds[buf];
-        *reinterpret_cast<float4 *>(&L[(ty + R) * P + RZ + 4 * tq]) = q[R];
+        lds_stv<V>(&L[(ty + R) * P + RZ + V * tq], q[R]);
 #pragma unroll
         for (int i = 0; i < NHT; ++i)
-            if (tid + i * 256 < NH) *reinterpret_cast<float4 *>(&L[h_lds[i]]) = hv[i];
+            if (tid + i * NT < NH) lds_stv<4>(&L[h_lds[i]], hv[i]);
 
         // injected terms of the cells this tile owns in plane x (rare)
         int inj_beg = 0, inj_end = 0;
@@ -153,13 +231,13 @@ __global__ __launch_bounds__(256) void step3d_kernel(Step3DArgs a)
             inj_beg = cptr[x];
             inj_end = cptr[x + 1];
             if (inj_beg < inj_end) {
-                *reinterpret_cast<float4 *>(&acc[4 * tid]) = make_float4(0.f, 0.f, 0.f, 0.f);
+                for (int j = tid; j < TY * TZ; j += NT) acc[j] = 0.f;
                 __syncthreads();
                 const float *vals = a.vals_inj + ((long)shot * a.nt + a.time) * a.inj_npoint;
                 const int32_t *uptr = a.uc_ptr + (long)inj_tab * (a.inj_kmax + 1);
                 const int32_t *ep = a.e_point + (long)inj_tab * a.inj_kmax;
                 const float *ew = a.e_w + (long)inj_tab * a.inj_kmax;
-                for (int j = inj_beg + tid; j < inj_end; j += 256) {
+                for (int j = inj_beg + tid; j < inj_end; j += NT) {
                     const long cj = (long)inj_tab * a.inj_kmax + j;
                     const int local = a.cell_local[cj];
                     const int u = a.cell_uc[cj];
@@ -173,105 +251,106 @@ __global__ __launch_bounds__(256) void step3d_kernel(Step3DArgs a)
         }
         __syncthreads();
 
-        // keep this plane's coefficients, then issue the next plane's loads before the arithmetic
-        const float4 mc4 = m4, ec4 = e4, oc4 = o4;
-        float4 um4, u04, up4, gv, iv;
-        long gs = 0;
-        if (GRAD) {
-            um4 = u04 = up4 = gv = iv = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (live) {
-                const long qs = (long)shot * a.u_shot_stride + col + (long)x * a.s0;
-                gs = (long)shot * a.g_shot_stride + col + (long)x * a.s0;
-                um4 = ld4(a.um + qs);
-                u04 = ld4(a.uc + qs);
-                up4 = ld4(a.up + qs);
-                gv = ld4(a.grad + gs);
-                if (a.illum) iv = ld4(a.illum + gs);
-            }
-        }
+        // request the next plane's ring before the arithmetic
         if (x + 1 < xb) {
 #pragma unroll
             for (int i = 0; i < NHT; ++i)
-                hv[i] = h_ok[i] ? ld4(cur + h_glb[i] + (long)(x + 1) * a.s0) : make_float4(0.f, 0.f, 0.f, 0.f);
+                if (h_ok[i]) ldv<4>(cur + (long)(x + 1) * sb, h_glb[i], hv[i]);
+        }
+        float um[V], u0[V], up[V], g[V], il[V];
+        char *gradb = nullptr, *illumb = nullptr;
+        if (GRAD) {
+#pragma unroll
+            for (int i = 0; i < V; ++i) um[i] = u0[i] = up[i] = g[i] = il[i] = 0.f;
+            gradb = reinterpret_cast<char *>(a.grad + (long)shot * a.g_shot_stride) + (long)x * sb;
+            illumb = a.illum ? reinterpret_cast<char *>(a.illum + (long)shot * a.g_shot_stride) + (long)x * sb : nullptr;
             if (live) {
-                m4 = ld4(a.m + col + (long)(x + 1) * a.s0);
-                e4 = ld4(a.eta + col + (long)(x + 1) * a.s0);
-                o4 = ld4(old + col + (long)(x + 1) * a.s0);
+                const long us = (long)shot * a.u_shot_stride * 4 + (long)x * sb;
+                ldv_stream<V>(reinterpret_cast<const char *>(a.um) + us, col, um);
+                ldv_stream<V>(reinterpret_cast<const char *>(a.uc) + us, col, u0);
+                ldv_stream<V>(reinterpret_cast<const char *>(a.up) + us, col, up);
+                ldv_stream<V>(gradb, col, g);
+                if (illumb) ldv_stream<V>(illumb, col, il);
             }
         }
 
         if (live) {
-            const float *ctr = &L[(ty + R) * P + RZ + 4 * tq];
-            float f[4 + 2 * RZ];
+            const float *ctr = &L[(ty + R) * P + RZ + V * tq];
+            // every neighbour value is folded into the sums as soon as it is read (one FMA per
+            // value and output: the same count as pairing symmetric neighbours first, with far
+            // shorter register live ranges)
+            float lap[V], uc[V];
 #pragma unroll
-            for (int s = 0; s < (4 + 2 * RZ) / 4; ++s) {
-                const float4 v = *reinterpret_cast<const float4 *>(ctr - RZ + 4 * s);
-                f[4 * s + 0] = v.x, f[4 * s + 1] = v.y, f[4 * s + 2] = v.z, f[4 * s + 3] = v.w;
+            for (int i = 0; i < V; ++i) lap[i] = 0.f;
+#pragma unroll
+            for (int s = 0; s < (V + 2 * RZ) / V; ++s) {
+                float fv[V];
+                lds_ldv<V>(ctr - RZ + V * s, fv);
+#pragma unroll
+                for (int e = 0; e < V; ++e) {
+                    const int pos = V * s + e - RZ;          // z offset of this value from output 0
+                    if (pos >= 0 && pos < V) uc[pos] = fv[e];
+#pragma unroll
+                    for (int i = 0; i < V; ++i) {
+                        const int d = pos - i;               // neighbour distance for output i
+                        if (d != 0 && d >= -R && d <= R) lap[i] += a.cz[d < 0 ? -d : d] * fv[e];
+                    }
+                }
             }
-            float lap[4], uc[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                uc[i] = f[RZ + i];
-                lap[i] = a.c0 * uc[i];
+            for (int i = 0; i < V; ++i) lap[i] += a.c0 * uc[i];
+#pragma unroll
+            for (int k = 1; k <= R; ++k) {
+                const float cyk = ISO ? a.cz[k] : a.cy[k];
+                float lo[V], hi[V];
+                lds_ldv<V>(ctr - k * P, lo);
+                lds_ldv<V>(ctr + k * P, hi);
+#pragma unroll
+                for (int i = 0; i < V; ++i) lap[i] += cyk * lo[i];
+#pragma unroll
+                for (int i = 0; i < V; ++i) lap[i] += cyk * hi[i];
             }
 #pragma unroll
             for (int k = 1; k <= R; ++k) {
+                const float cxk = ISO ? a.cz[k] : a.cx[k];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) lap[i] += a.cz[k] * (f[RZ + i - k] + f[RZ + i + k]);
+                for (int i = 0; i < V; ++i) lap[i] += cxk * q[R - k][i];
+#pragma unroll
+                for (int i = 0; i < V; ++i) lap[i] += cxk * q[R + k][i];
             }
+            float res[V];
 #pragma unroll
-            for (int k = 1; k <= R; ++k) {
-                const float4 lo = *reinterpret_cast<const float4 *>(ctr - k * P);
-                const float4 hi = *reinterpret_cast<const float4 *>(ctr + k * P);
-                lap[0] += a.cy[k] * (lo.x + hi.x);
-                lap[1] += a.cy[k] * (lo.y + hi.y);
-                lap[2] += a.cy[k] * (lo.z + hi.z);
-                lap[3] += a.cy[k] * (lo.w + hi.w);
-            }
-#pragma unroll
-            for (int k = 1; k <= R; ++k) {
-                const float4 lo = q[R - k], hi = q[R + k];
-                lap[0] += a.cx[k] * (lo.x + hi.x);
-                lap[1] += a.cx[k] * (lo.y + hi.y);
-                lap[2] += a.cx[k] * (lo.z + hi.z);
-                lap[3] += a.cx[k] * (lo.w + hi.w);
-            }
-            const float mm[4] = {mc4.x, mc4.y, mc4.z, mc4.w}, ee[4] = {ec4.x, ec4.y, ec4.z, ec4.w},
-                        oo[4] = {oc4.x, oc4.y, oc4.z, oc4.w};
-            float res[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < V; ++i) {
                 const float ed = ee[i] * a.dt;
                 res[i] = fast_div3(a.dt2 * lap[i] + 2.0f * mm[i] * uc[i] - mm[i] * oo[i] + ed * uc[i], mm[i] + ed);
             }
             if (inj_beg < inj_end) {
-                const float4 add = *reinterpret_cast<const float4 *>(&acc[4 * tid]);
-                res[0] += add.x, res[1] += add.y, res[2] += add.z, res[3] += add.w;
+#pragma unroll
+                for (int i = 0; i < V; ++i) res[i] += acc[ty * TZ + V * tq + i];
             }
-            const long ps = col + (long)x * a.s0;
             if (full) {
-                *reinterpret_cast<float4 *>(out + ps) = make_float4(res[0], res[1], res[2], res[3]);
+                stv_stream<V>(out + (long)x * sb, col, res);
             } else {
-                for (int i = 0; i < 4; ++i)
-                    if (z + i < a.n2) out[ps + i] = res[i];
+                float *po = reinterpret_cast<float *>(out + (long)x * sb + col);
+                for (int i = 0; i < V; ++i)
+                    if (z + i < a.n2) po[i] = res[i];
             }
             if (GRAD) {
-                const float um[4] = {um4.x, um4.y, um4.z, um4.w}, u0[4] = {u04.x, u04.y, u04.z, u04.w},
-                            up[4] = {up4.x, up4.y, up4.z, up4.w};
-                float g[4] = {gv.x, gv.y, gv.z, gv.w}, il[4] = {iv.x, iv.y, iv.z, iv.w};
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
+                for (int i = 0; i < V; ++i) {
                     g[i] += -((um[i] - 2.0f * u0[i] + up[i]) * a.inv_dt2) * uc[i];
                     il[i] += u0[i] * u0[i] + (a.first ? up[i] * up[i] : 0.0f);
                 }
                 if (full) {
-                    *reinterpret_cast<float4 *>(a.grad + gs) = make_float4(g[0], g[1], g[2], g[3]);
-                    if (a.illum) *reinterpret_cast<float4 *>(a.illum + gs) = make_float4(il[0], il[1], il[2], il[3]);
+                    stv_stream<V>(gradb, col, g);
+                    if (illumb) stv_stream<V>(illumb, col, il);
                 } else {
-                    for (int i = 0; i < 4; ++i)
+                    float *pg = reinterpret_cast<float *>(gradb + col);
+                    float *pi = illumb ? reinterpret_cast<float *>(illumb + col) : nullptr;
+                    for (int i = 0; i < V; ++i)
                         if (z + i < a.n2) {
-                            a.grad[gs + i] = g[i];
-                            if (a.illum) a.illum[gs + i] = il[i];
+                            pg[i] = g[i];
+                            if (pi) pi[i] = il[i];
                         }
                 }
             }
@@ -281,29 +360,44 @@ __global__ __launch_bounds__(256) void step3d_kernel(Step3DArgs a)
     }
 }
 
-template <int R>
-static int launch_r3(const Plan &p, const Step3DArgs &a, int nblocks, hipStream_t stream)
+template <int R, int V, bool ISO>
+static int launch_r3v(const Plan &p, const Step3DArgs &a, hipStream_t stream)
 {
+    constexpr int NT = 16 * 64 / V;
+    const int nitp = a.pt_idx ? (((a.itp_npoint + NT - 1) / NT) * a.nshots + 7) / 8 * 8 : 0;
+    const int nblocks = (a.nwork + 7) / 8 * 8 + nitp;
     if (a.um)
-        hipLaunchKernelGGL((step3d_kernel<R, 16, 64, true>), dim3(nblocks), dim3(256), 0, stream, a);
+        hipLaunchKernelGGL((step3d_kernel<R, 16, 64, V, true, ISO>), dim3(nblocks), dim3(NT), 0, stream, a);
     else
-        hipLaunchKernelGGL((step3d_kernel<R, 16, 64, false>), dim3(nblocks), dim3(256), 0, stream, a);
+        hipLaunchKernelGGL((step3d_kernel<R, 16, 64, V, false, ISO>), dim3(nblocks), dim3(NT), 0, stream, a);
     MIFWI_HIP(hipGetLastError());
     return MIFWI_OK;
 }
 
+template <int R>
+static int launch_r3(const Plan &p, const Step3DArgs &a, hipStream_t stream)
+{
+    // equal spacing in all three dimensions: one coefficient set instead of three (fewer SGPRs)
+    bool iso = true;
+    for (int k = 0; k <= R; ++k) iso = iso && a.cx[k] == a.cz[k] && a.cy[k] == a.cz[k];
+    // wide stencils keep a long register queue per point: two points per thread (512 threads) keep
+    // the register count low enough for 4 waves per SIMD; narrow ones run four points per thread
+    const bool two = p.vec3d ? (p.vec3d == 2) : (R > 4);
+    if (two) return iso ? launch_r3v<R, 2, true>(p, a, stream) : launch_r3v<R, 2, false>(p, a, stream);
+    return iso ? launch_r3v<R, 4, true>(p, a, stream) : launch_r3v<R, 4, false>(p, a, stream);
+}
+
 int launch_step3d(const Plan &p, const Step3DArgs &a, hipStream_t stream)
 {
-    const int nblocks = (a.nwork + 7) / 8 * 8 + (a.pt_idx ? (((a.itp_npoint + 255) / 256) * a.nshots + 7) / 8 * 8 : 0);
     switch (p.L.R) {
-        case 1: return launch_r3<1>(p, a, nblocks, stream);
-        case 2: return launch_r3<2>(p, a, nblocks, stream);
-        case 3: return launch_r3<3>(p, a, nblocks, stream);
-        case 4: return launch_r3<4>(p, a, nblocks, stream);
-        case 5: return launch_r3<5>(p, a, nblocks, stream);
-        case 6: return launch_r3<6>(p, a, nblocks, stream);
-        case 7: return launch_r3<7>(p, a, nblocks, stream);
-        case 8: return launch_r3<8>(p, a, nblocks, stream);
+        case 1: return launch_r3<1>(p, a, stream);
+        case 2: return launch_r3<2>(p, a, stream);
+        case 3: return launch_r3<3>(p, a, stream);
+        case 4: return launch_r3<4>(p, a, stream);
+        case 5: return launch_r3<5>(p, a, stream);
+        case 6: return launch_r3<6>(p, a, stream);
+        case 7: return launch_r3<7>(p, a, stream);
+        case 8: return launch_r3<8>(p, a, stream);
     }
     set_error("unsupported stencil radius");
     return MIFWI_EINVAL;

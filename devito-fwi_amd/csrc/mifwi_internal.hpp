@@ -125,6 +125,7 @@ struct Plan {
     int kind = 0;
     int tile_tx = 0, tile_tz = 0, ntx = 0, ntz = 0;
     int xchunk = 0, nchunk = 0;
+    int vec3d = 0;  // points per thread of the 2.5-D kernel: 0 = by stencil radius, else 2 or 4
 
     // captured time loops: (loop kind, nshots, variant a, variant b, group) -> executable graph + launches
     std::map<std::tuple<int, int, int, int, int>, std::pair<hipGraphExec_t, int>> graphs;

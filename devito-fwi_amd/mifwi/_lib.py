@@ -46,7 +46,8 @@ _LIB = None
 
 
 def library_path():
-    return os.path.join(os.path.dirname(_HERE), "libmifwi.so")
+    # MIFWI_LIB selects another build of the same library (kernel tuning experiments)
+    return os.environ.get("MIFWI_LIB") or os.path.join(os.path.dirname(_HERE), "libmifwi.so")
 
 
 def load_library():
