@@ -84,9 +84,12 @@ __device__ inline void lds_stv(float *p, const float (&d)[V])
 }
 
 // R: stencil radius.  TY x TZ: tile of the (y, z) plane.  V: points per thread (TY*TZ/V threads).
+// Register budget: the propagation variants are held to 168 VGPRs (3 blocks of 256 threads per CU;
+// at radius 8 that is 165 without spilling and worth +8 % over 2 blocks), the gradient variant,
+// which carries five more vectors, to 2 blocks per CU.
 // GRAD: also accumulate the FWI gradient.  ISO: equal spacing in x, y and z (one coefficient set).
 template <int R, int TY, int TZ, int V, bool GRAD, bool ISO>
-__global__ __launch_bounds__(TY *TZ / V) void step3d_kernel(Step3DArgs a)
+__global__ __launch_bounds__(TY *TZ / V, (GRAD ? 2 : 3) * (TY * TZ / V) / 256) void step3d_kernel(Step3DArgs a)
 {
     constexpr int NT = TY * TZ / V;                     // threads per block
     constexpr int RZ = (R + 3) / 4 * 4;
@@ -174,6 +177,8 @@ __global__ __launch_bounds__(TY *TZ / V) void step3d_kernel(Step3DArgs a)
         h_glb[i] = (unsigned)((a.off0 + (long)gy * a.s1 + (z0 - RZ + 4 * c4)) * 4);
     }
 
+    const unsigned char *ezero = a.eta_zero ? a.eta_zero + (long)tile * a.n0 : nullptr;
+
     // injection work of this block: CSR over (tile, plane), ranges for the whole chunk
     const int inj_tab = a.inj_per_shot ? shot : 0;
     const int32_t *cptr = a.cell_ptr ? a.cell_ptr + ((long)inj_tab * a.nty * a.ntz + tile) * (a.n0 + 1) : nullptr;
@@ -212,9 +217,11 @@ __global__ __launch_bounds__(TY *TZ / V) void step3d_kernel(Step3DArgs a)
         float mm[V], ee[V], oo[V];
 #pragma unroll
         for (int i = 0; i < V; ++i) mm[i] = 1.f, ee[i] = 0.f, oo[i] = 0.f;
+        // planes of the tile where the sponge is identically zero skip its 4 bytes per point
+        const bool eta_is_zero = ezero ? (ezero[x] != 0) : false;   // block-uniform
         if (live) {
             ldv_stream<V>(mb + (long)x * sb, col, mm);
-            ldv_stream<V>(eb + (long)x * sb, col, ee);
+            if (!eta_is_zero) ldv_stream<V>(eb + (long)x * sb, col, ee);
             ldv_stream<V>(old + (long)x * sb, col, oo);
         }
 
@@ -360,6 +367,30 @@ __global__ __launch_bounds__(TY *TZ / V) void step3d_kernel(Step3DArgs a)
     }
 }
 
+// eta_zero[tile][x] = 1 when the sponge field vanishes on the whole (tile, plane) patch
+__global__ void eta_zero_kernel(const float *eta, unsigned char *flags, int n0, int n1, int n2, long s0, long s1,
+                                long off0, int ntz, int TY, int TZ)
+{
+    const int tile = blockIdx.x / n0, x = blockIdx.x - tile * n0;
+    const int y0 = (tile / ntz) * TY, z0 = (tile % ntz) * TZ;
+    int nonzero = 0;
+    for (int i = threadIdx.x; i < TY * TZ; i += blockDim.x) {
+        const int y = y0 + i / TZ, z = z0 + i % TZ;
+        if (y < n1 && z < n2 && eta[off0 + (long)x * s0 + (long)y * s1 + z] != 0.f) nonzero = 1;
+    }
+    nonzero = __syncthreads_or(nonzero);
+    if (threadIdx.x == 0) flags[blockIdx.x] = nonzero ? 0 : 1;
+}
+
+int launch_eta_zero(const Plan &p, unsigned char *flags)
+{
+    const int nblocks = p.ntx * p.ntz * p.L.n[0];
+    hipLaunchKernelGGL(eta_zero_kernel, dim3(nblocks), dim3(256), 0, p.stream, (const float *)p.eta, flags, p.L.n[0],
+                       p.L.n[1], p.L.n[2], p.L.s0, p.L.s1, p.L.off0, p.ntz, p.tile_tx, p.tile_tz);
+    MIFWI_HIP(hipGetLastError());
+    return MIFWI_OK;
+}
+
 template <int R, int V, bool ISO>
 static int launch_r3v(const Plan &p, const Step3DArgs &a, hipStream_t stream)
 {
@@ -375,14 +406,42 @@ static int launch_r3v(const Plan &p, const Step3DArgs &a, hipStream_t stream)
 }
 
 template <int R>
+static int occupancy_r3(bool grad)
+{
+    int nb = 0;
+    hipError_t e = grad ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, step3d_kernel<R, 16, 64, 4, true, true>, 256, 0)
+                        : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, step3d_kernel<R, 16, 64, 4, false, true>, 256, 0);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        return 2;
+    }
+    return nb < 1 ? 1 : nb;
+}
+
+// resident blocks per CU of the 2.5-D kernel for this radius (used to size the x chunks)
+int step3d_blocks_per_cu(int R, bool grad)
+{
+    switch (R) {
+        case 1: return occupancy_r3<1>(grad);
+        case 2: return occupancy_r3<2>(grad);
+        case 3: return occupancy_r3<3>(grad);
+        case 4: return occupancy_r3<4>(grad);
+        case 5: return occupancy_r3<5>(grad);
+        case 6: return occupancy_r3<6>(grad);
+        case 7: return occupancy_r3<7>(grad);
+        default: return occupancy_r3<8>(grad);
+    }
+}
+
+template <int R>
 static int launch_r3(const Plan &p, const Step3DArgs &a, hipStream_t stream)
 {
     // equal spacing in all three dimensions: one coefficient set instead of three (fewer SGPRs)
     bool iso = true;
     for (int k = 0; k <= R; ++k) iso = iso && a.cx[k] == a.cz[k] && a.cy[k] == a.cz[k];
-    // wide stencils keep a long register queue per point: two points per thread (512 threads) keep
-    // the register count low enough for 4 waves per SIMD; narrow ones run four points per thread
-    const bool two = p.vec3d ? (p.vec3d == 2) : (R > 4);
+    // four points per thread (256 threads) by default; two points per thread (512 threads, twice the
+    // waves at half the registers) measured slower at every order and is kept for experiments
+    const bool two = (p.vec3d == 2);
     if (two) return iso ? launch_r3v<R, 2, true>(p, a, stream) : launch_r3v<R, 2, false>(p, a, stream);
     return iso ? launch_r3v<R, 4, true>(p, a, stream) : launch_r3v<R, 4, false>(p, a, stream);
 }

@@ -159,6 +159,7 @@ static void destroy(Plan *p)
     dev_free(p->d_dense);
     dev_free(p->d_partial);
     dev_free(p->d_fval);
+    dev_free(p->eta_zero);
     if (p->ev0) (void)hipEventDestroy(p->ev0);
     if (p->ev1) (void)hipEventDestroy(p->ev1);
     if (p->own_stream && p->stream) (void)hipStreamDestroy(p->stream);
@@ -441,11 +442,11 @@ static int create(const mifwi_config *cfg, mifwi_plan **out)
         p->tile_tx = 16, p->tile_tz = 64;
         p->ntx = (p->L.n[1] + 15) / 16;
         p->ntz = (p->L.n[2] + 63) / 64;
-        const int want = (1536 + p->ntx * p->ntz * cfg->max_shots - 1) / (p->ntx * p->ntz * cfg->max_shots);
-        const int min_chunk = std::max(8, 2 * p->L.R);
-        p->nchunk = std::max(1, std::min(want, p->L.n[0] / min_chunk));
-        p->xchunk = (p->L.n[0] + p->nchunk - 1) / p->nchunk;
-        p->nchunk = (p->L.n[0] + p->xchunk - 1) / p->xchunk;
+        hipDeviceProp_t prop{};
+        if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) p->ncu = prop.multiProcessorCount;
+        p->bpc_fwd = step3d_blocks_per_cu(p->L.R, false);
+        p->bpc_grad = step3d_blocks_per_cu(p->L.R, true);
+        if (const char *env = getenv("MIFWI_3D_NCHUNK")) p->nchunk_env = std::max(1, atoi(env));  // tuning experiments
     }
     auto bail = [&](int code) {
         destroy(p);
@@ -494,6 +495,10 @@ static int set_model(Plan &p, const void *vp, const void *damp)
         damp_dev = ddamp;
     }
     if ((rc = launch_prep_model<T>(p, vp_dev, damp_dev, (T *)p.m, (T *)p.eta))) return rc;
+    if (p.kind == 2) {
+        if (!p.eta_zero && (rc = dev_alloc(p, (void **)&p.eta_zero, (size_t)p.ntx * p.ntz * p.L.n[0], true))) return rc;
+        if ((rc = launch_eta_zero(p, p.eta_zero))) return rc;
+    }
     p.have_model = true;
     // pageable host sources must not be reused by the caller before the copy has happened
     MIFWI_HIP(hipStreamSynchronize(p.stream));
@@ -609,7 +614,36 @@ static void set_interp(Step2DArgs &a, const SparseSet &S, void *vals_out)
 }
 
 // constants of the 2.5-D kernel
-static Step3DArgs base3d(const Plan &p, int nshots)
+// Split x into chunks so that one launch fills the GPU an almost whole number of times.
+// Every block primes its register queue with 2R extra planes, so few chunks would be cheapest, but
+// blocks differ in cost (sponge-free planes skip a load, edge tiles are partly empty) and only a
+// launch of several rounds of blocks balances that.  Measured on 592^3 (MI355X, 3 blocks/CU):
+// tail efficiency (rounds / ceil(rounds)) explains the dips (3 chunks: 1.45 rounds, -15 %), and
+// among well-filled choices 3-4 rounds ran 5-9 % faster than 1-2.
+static void choose_chunks(const Plan &p, int nshots, bool grad, int &nchunk, int &xchunk)
+{
+    const int n0 = p.L.n[0];
+    const int min_chunk = std::max(8, 2 * p.L.R);
+    const int max_chunks = std::max(1, std::min(16, n0 / min_chunk));
+    const double slots = (double)p.ncu * (grad ? p.bpc_grad : p.bpc_fwd);
+    int best = 1;
+    double best_score = -1.0;
+    for (int nc = 1; nc <= max_chunks; ++nc) {
+        const int xc = (n0 + nc - 1) / nc;
+        const int real_nc = (n0 + xc - 1) / xc;
+        const double rounds = (double)p.ntx * p.ntz * real_nc * nshots / slots;
+        const double tail = rounds / std::ceil(rounds);
+        const double prime = (double)xc / (xc + 2 * p.L.R);
+        const double balance = std::min(1.0, 0.85 + 0.05 * rounds);   // saturates at 3 rounds
+        const double score = tail * balance * std::pow(prime, 0.35);
+        if (score > best_score) best_score = score, best = nc;
+    }
+    if (p.nchunk_env) best = std::min(p.nchunk_env, max_chunks);
+    xchunk = (n0 + best - 1) / best;
+    nchunk = (n0 + xchunk - 1) / xchunk;
+}
+
+static Step3DArgs base3d(const Plan &p, int nshots, bool grad)
 {
     Step3DArgs a{};
     double w[kMaxR + 1];
@@ -633,10 +667,10 @@ static Step3DArgs base3d(const Plan &p, int nshots)
     a.off0 = p.L.off0;
     a.nty = p.ntx;
     a.ntz = p.ntz;
-    a.nchunk = p.nchunk;
-    a.xchunk = p.xchunk;
+    choose_chunks(p, nshots, grad, a.nchunk, a.xchunk);
     a.nshots = nshots;
-    a.nwork = p.ntx * p.ntz * p.nchunk * nshots;
+    a.nwork = p.ntx * p.ntz * a.nchunk * nshots;
+    a.eta_zero = p.eta_zero;
     a.m = (const float *)p.m;
     a.eta = (const float *)p.eta;
     a.nt = p.cfg.nt;
@@ -763,7 +797,7 @@ static int run_forward(Plan &p, int nshots, int save)
         }
     }
     if (p.kind == 2) {
-        Step3DArgs a = base3d(p, nsh);
+        Step3DArgs a = base3d(p, nsh, false);
         a.shot_stride = shot_stride;
         set_inject3(a, p.src, p.d_wavelet);
         set_interp3(a, p.rec, p.d_rec);
@@ -866,7 +900,7 @@ static int run_backward(Plan &p, int nshots, bool with_grad, bool with_illum)
         }
     }
     if (p.kind == 2) {
-        Step3DArgs a = base3d(p, nsh);
+        Step3DArgs a = base3d(p, nsh, with_grad);
         a.shot_stride = shot_stride;
         set_inject3(a, p.rec, p.d_res);
         if (!with_grad) set_interp3(a, p.src, p.d_srca);

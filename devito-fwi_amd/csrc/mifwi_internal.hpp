@@ -125,6 +125,9 @@ struct Plan {
     int kind = 0;
     int tile_tx = 0, tile_tz = 0, ntx = 0, ntz = 0;
     int xchunk = 0, nchunk = 0;
+    int ncu = 256, bpc_fwd = 2, bpc_grad = 2;  // CUs and resident 2.5-D blocks per CU (plain / gradient)
+    int nchunk_env = 0;
+    unsigned char *eta_zero = nullptr;  // 2.5-D kernel: [tile][n0] flags of sponge-free patches
     int vec3d = 0;  // points per thread of the 2.5-D kernel: 0 = by stencil radius, else 2 or 4
 
     // captured time loops: (loop kind, nshots, variant a, variant b, group) -> executable graph + launches
@@ -249,6 +252,7 @@ struct Step3DArgs {
     int n0, n1, n2;
     long s0, s1, off0;
     int nty, ntz, nchunk, xchunk, nwork, nshots;
+    const unsigned char *eta_zero;   // [tile][n0] sponge-free flags, or null
     // gradient (um == nullptr: plain propagation)
     const float *um, *uc, *up;
     long u_shot_stride;
@@ -268,5 +272,7 @@ struct Step3DArgs {
     int time, nt;
 };
 int launch_step3d(const Plan &p, const Step3DArgs &a, hipStream_t stream);
+int launch_eta_zero(const Plan &p, unsigned char *flags);
+int step3d_blocks_per_cu(int R, bool grad);
 
 }  // namespace mifwi

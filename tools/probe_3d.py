@@ -44,4 +44,14 @@ for so in orders:
         best = min(best, st["bwd_ms"] / st["bwd_launches"])
     print("so=%2d grid %s adj  %.3f ms/step  %.1f Gpts/s  %.0f GB/s algorithmic" %
           (so, sp, best, ngrid / best / 1e6, 20 * ngrid / best / 1e6), flush=True)
+    if os.environ.get("PROBE_GRAD"):
+        u = np.zeros((nt,) + tuple(sp), dtype=np.float32) if False else None
+        plan.forward(wav, save=True, want_rec=False)
+        best = 1e9
+        for _ in range(3):
+            plan.gradient(recd, want_illum=False)
+            st = plan.stats()
+            best = min(best, st["bwd_ms"] / st["bwd_launches"])
+        print("so=%2d grid %s grad %.3f ms/step  %.1f Gpts/s  %.0f GB/s algorithmic (32 B/pt)" %
+              (so, sp, best, ngrid / best / 1e6, 32 * ngrid / best / 1e6), flush=True)
     plan.close()
