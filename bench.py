@@ -34,6 +34,16 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak
 SHOTS_PER_GPU = 8
 
 
+def pmc_traffic(kernel):
+    """HBM-side bytes per launch of `kernel` from the committed rocprofv3 PMC passes of this same
+    command (profiles/r1_traffic.json), or None when no such measurement is recorded."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r1_traffic.json")) as f:
+            return json.load(f).get(kernel, {}).get("bytes")
+    except (OSError, ValueError):
+        return None
+
+
 def marmousi2(space_order):
     """Marmousi-II set-up of the reference's marmousi2_fwi.py:61-103 (rasters are the reference's
     model_data/SMARM2 files, kept as fixtures)."""
@@ -79,6 +89,45 @@ def cpu_baseline(true_model, init_model, src, rec, wavelet, dt, space_order, nsh
                       "full nt=%d), shots serial, OpenMP over the grid; %.1f s" % (nshots, wavelet.shape[0], el)}
 
 
+def roofline_3d(mifwi, device, space_order=16, n=512, nbl=40, nt=14):
+    """Forward time step of the 2.5-D kernel on the synthetic 3-D stress grid (512^3 + sponge = 592^3,
+    one shot): algorithmic 20 B per point update / kernel duration (HIP events around the time loop
+    on the plan's stream; one launch per step, launches last ~1 ms so gaps are negligible)."""
+    from seismic import Model
+    shape = (n, n, n)
+    vp = np.empty(shape, dtype=np.float32)
+    vp[:] = np.linspace(1.5, 4.5, n, dtype=np.float32)[None, None, :]
+    model = Model(origin=(0., 0., 0.), spacing=(10., 10., 10.), shape=shape, space_order=space_order, vp=vp,
+                  nbl=nbl, bcs="damp")
+    dt = float(model.critical_dt)
+    sp = model.grid.shape
+    ngrid = float(np.prod(sp))
+    src = np.array([[n * 5.0, n * 5.0, 20.0]], dtype=np.float32)
+    g = np.linspace(0, (n - 1) * 10.0, 64, dtype=np.float32)
+    rec = np.stack(np.meshgrid(g, g, indexing="ij"), -1).reshape(-1, 2)
+    rec = np.concatenate([rec, np.full((rec.shape[0], 1), 20.0, np.float32)], 1)
+    plan = mifwi.Plan(sp, model.spacing, model.grid.origin, space_order, nt, dt, 1, rec.shape[0], max_shots=1,
+                      device=device)
+    plan.set_model(model.vp.data, model.damp.data)
+    plan.set_geometry(src, rec)
+    t = np.arange(nt) * dt
+    r = np.pi * 0.010 * (t - 100.0)
+    wav = ((1 - 2 * r ** 2) * np.exp(-r ** 2)).astype(np.float32).reshape(nt, 1)
+    best = None
+    for _ in range(3):
+        plan.forward(wav, save=False, want_rec=False)
+        st = plan.stats()
+        ms = st["fwd_ms"] / st["fwd_launches"]
+        best = ms if best is None else min(best, ms)
+    plan.close()
+    ach = 20.0 * ngrid / (best * 1e-3) / 1e9
+    return {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+            "traffic": pmc_traffic("step3d_kernel"), "kernel": "step3d_kernel", "avg_launch_us": best * 1e3,
+            "gpoints_per_s": ngrid / (best * 1e-3) / 1e9,
+            "workload": "synthetic 3-D %d^3 (+nbl %d = %d^3), space_order=%d, 1 shot, forward time step"
+                        % (n, nbl, sp[0], space_order)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -86,6 +135,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--space-order", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-3d", action="store_true", help="skip the 3-D stencil roofline measurement")
     ap.add_argument("--flags", type=int, default=0, help="MIFWI_FLAG_* bits for the plan (debugging)")
     args = ap.parse_args()
 
@@ -191,14 +241,14 @@ def main():
     g_ach = g_bytes_loop / (bwd_ms * 1e-3) / 1e9
     f_ach = f_bytes_loop / (fwd_ms * 1e-3) / 1e9
     roofline = {"bound": "hbm", "achieved": g_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": g_ach / HBM_PEAK_GBS, "traffic": None,
+                "frac": g_ach / HBM_PEAK_GBS, "traffic": pmc_traffic(st["bwd_kernel"]),
                 "kernel": st["bwd_kernel"], "launches_per_loop": bwd_launches,
                 "avg_launch_us": bwd_ms * 1e3 / max(1, bwd_launches),
                 "bytes_per_launch": g_bytes_loop / max(1, bwd_launches),
                 "timing": "HIP events around the backward time loop on the plan's stream / launches "
                           "(includes inter-kernel gaps)"}
     roofline_fwd = {"bound": "hbm", "achieved": f_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": f_ach / HBM_PEAK_GBS, "traffic": None, "kernel": st["fwd_kernel"],
+                    "frac": f_ach / HBM_PEAK_GBS, "traffic": pmc_traffic(st["fwd_kernel"]), "kernel": st["fwd_kernel"],
                     "launches_per_loop": fwd_launches, "avg_launch_us": fwd_ms * 1e3 / max(1, fwd_launches)}
 
     out = {
@@ -218,11 +268,14 @@ def main():
         "objective": fval,
         "roofline": roofline, "roofline_forward": roofline_fwd,
     }
+    plan.close()
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(true_model, init_model, src_all, rec, wavelet, dt, so)
+    if rank == 0 and world == 1 and not args.no_3d:
+        # the north-star stencil: 16th-order 3-D forward step against the HBM roofline
+        out["roofline_3d"] = roofline_3d(mifwi, local_rank, space_order=16)
     if rank == 0:
         print(json.dumps(out))
-    plan.close()
     if world > 1:
         dist.destroy_process_group()
 
