@@ -21,9 +21,12 @@ namespace mifwi {
 
 __device__ inline float fast_div3(float a, float b)
 {
+    // a / b without the IEEE division sequence: reciprocal, one Newton step on it, then one
+    // residual correction of the quotient (q += r * (a - b q)), which leaves it within 1 ulp
     float r = __builtin_amdgcn_rcpf(b);
-    r = r * (2.0f - b * r);
-    return a * r;
+    r = __builtin_fmaf(__builtin_fmaf(-b, r, 1.0f), r, r);
+    float q = a * r;
+    return __builtin_fmaf(__builtin_fmaf(-b, q, a), r, q);
 }
 
 // V consecutive floats (V = 2 or 4) moved with one aligned 8- or 16-byte access.

@@ -23,10 +23,12 @@ namespace mifwi {
 
 __device__ inline float fast_div(float a, float b)
 {
-    // reciprocal + one Newton step: relative error ~1e-7, far inside the parity budget
+    // a / b without the IEEE division sequence: reciprocal, one Newton step on it, then one
+    // residual correction of the quotient (q += r * (a - b q)), which leaves it within 1 ulp
     float r = __builtin_amdgcn_rcpf(b);
-    r = r * (2.0f - b * r);
-    return a * r;
+    r = __builtin_fmaf(__builtin_fmaf(-b, r, 1.0f), r, r);
+    float q = a * r;
+    return __builtin_fmaf(__builtin_fmaf(-b, q, a), r, q);
 }
 
 template <int R, int TX, int TZ, bool GRAD>

@@ -193,6 +193,40 @@ def _wavelet(geometry):
     return _shot_geometry(geometry, 0).src.data
 
 
+def _compute_batch(geometry, shots, obs, direct_wave, misfit_func, calc_grad):
+    """Objective pieces of the shots `shots` (indices into the survey) as one GPU batch:
+    (fvals per shot, residuals (ns, nt, nrec), padded-grid gradients (ns, *grid) or None,
+    illumination likewise).  With the least-squares misfit and no direct wave the residual is
+    formed on the device; otherwise the misfit runs on the host between the two passes."""
+    model = geometry.model
+    entry = _batch_entry(geometry, shots)
+    plan = entry.plan
+    ns = len(shots)
+    wavelet = _wavelet(geometry)
+    obs_b = np.stack([obs[i].data for i in shots]).astype(model.dtype, copy=False)
+    dw_b = None
+    if direct_wave is not None:
+        dw_b = np.stack([direct_wave[i].data for i in shots]).astype(model.dtype, copy=False)
+    if misfit_func is least_square and dw_b is None:
+        out = plan.l2_misfit_gradient(wavelet, obs_b, nshots=ns, calc_grad=calc_grad, want_illum=True,
+                                      want_residual=True)
+        return out['fval'], out['residual'], out['grad'], out['illum']
+    syn_b = plan.forward(wavelet, nshots=ns, save=calc_grad)
+    res_b = np.empty_like(syn_b)
+    fvals = []
+    for k in range(ns):
+        s_, o_ = syn_b[k], obs_b[k]
+        if dw_b is not None:
+            s_, o_ = s_ - dw_b[k], o_ - dw_b[k]
+        f_, r_ = misfit_func(s_, o_)
+        fvals.append(f_)
+        res_b[k] = r_
+    g_b = il_b = None
+    if calc_grad:
+        g_b, il_b = plan.gradient(res_b, nshots=ns, want_illum=True)
+    return fvals, res_b, g_b, il_b
+
+
 # ---------------------------------------------------------------------------------------------
 # modelling
 # ---------------------------------------------------------------------------------------------
@@ -291,33 +325,8 @@ def fwi_obj_multi(geometry, obs, misfit_func, direct_wave=None, mask=None, preco
                 grad += g_
                 illum += il_
     elif mine:
-        entry = _batch_entry(geometry, mine)
-        plan = entry.plan
-        ns = len(mine)
-        wavelet = _wavelet(geometry)
-        obs_b = np.stack([obs[i].data for i in mine]).astype(model.dtype, copy=False)
-        dw_b = None
-        if direct_wave is not None:
-            dw_b = np.stack([direct_wave[i].data for i in mine]).astype(model.dtype, copy=False)
+        fvals, res_b, g_b, il_b = _compute_batch(geometry, mine, obs, direct_wave, misfit_func, calc_grad)
         crop = tuple(slice(nbl, -nbl) if nbl else slice(None) for _ in range(model.dim))
-        if misfit_func is least_square and dw_b is None:
-            out = plan.l2_misfit_gradient(wavelet, obs_b, nshots=ns, calc_grad=calc_grad, want_illum=True,
-                                          want_residual=True)
-            res_b, fvals, g_b, il_b = out['residual'], out['fval'], out['grad'], out['illum']
-        else:
-            syn_b = plan.forward(wavelet, nshots=ns, save=calc_grad)
-            res_b = np.empty_like(syn_b)
-            fvals = []
-            for k in range(ns):
-                s_, o_ = syn_b[k], obs_b[k]
-                if dw_b is not None:
-                    s_, o_ = s_ - dw_b[k], o_ - dw_b[k]
-                f_, r_ = misfit_func(s_, o_)
-                fvals.append(f_)
-                res_b[k] = r_
-            g_b = il_b = None
-            if calc_grad:
-                g_b, il_b = plan.gradient(res_b, nshots=ns, want_illum=True)
         for k, i in enumerate(mine):
             fval += float(fvals[k])
             residuals[i] = res_b[k]
