@@ -267,18 +267,17 @@ __global__ __launch_bounds__(TY *TZ / V, (GRAD ? 2 : 3) * (TY * TZ / V) / 256) v
             for (int i = 0; i < NHT; ++i)
                 if (h_ok[i]) ldv<4>(cur + (long)(x + 1) * sb, h_glb[i], hv[i]);
         }
-        float um[V], u0[V], up[V], g[V], il[V];
+        float u0[V], up[V], g[V], il[V];
         char *gradb = nullptr, *illumb = nullptr;
         if (GRAD) {
 #pragma unroll
-            for (int i = 0; i < V; ++i) um[i] = u0[i] = up[i] = g[i] = il[i] = 0.f;
+            for (int i = 0; i < V; ++i) u0[i] = up[i] = g[i] = il[i] = 0.f;
             gradb = reinterpret_cast<char *>(a.grad + (long)shot * a.g_shot_stride) + (long)x * sb;
             illumb = a.illum ? reinterpret_cast<char *>(a.illum + (long)shot * a.g_shot_stride) + (long)x * sb : nullptr;
             if (live) {
                 const long us = (long)shot * a.u_shot_stride * 4 + (long)x * sb;
-                ldv_stream<V>(reinterpret_cast<const char *>(a.um) + us, col, um);
                 ldv_stream<V>(reinterpret_cast<const char *>(a.uc) + us, col, u0);
-                ldv_stream<V>(reinterpret_cast<const char *>(a.up) + us, col, up);
+                if (a.first && illumb) ldv_stream<V>(reinterpret_cast<const char *>(a.up) + us, col, up);
                 ldv_stream<V>(gradb, col, g);
                 if (illumb) ldv_stream<V>(illumb, col, il);
             }
@@ -348,8 +347,10 @@ __global__ __launch_bounds__(TY *TZ / V, (GRAD ? 2 : 3) * (TY * TZ / V) / 256) v
             if (GRAD) {
 #pragma unroll
                 for (int i = 0; i < V; ++i) {
-                    g[i] += -((um[i] - 2.0f * u0[i] + up[i]) * a.inv_dt2) * uc[i];
-                    il[i] += u0[i] * u0[i] + (a.first ? up[i] * up[i] : 0.0f);
+                    // correlation summed by parts over time (see kernels_tiled2d.hip): second time
+                    // difference of the backward field, one saved forward level per step
+                    g[i] += -((oo[i] - 2.0f * uc[i] + res[i]) * a.inv_dt2) * u0[i];
+                    il[i] += u0[i] * u0[i] + up[i] * up[i];
                 }
                 if (full) {
                     stv_stream<V>(gradb, col, g);

@@ -16,7 +16,11 @@
 // Block ids are dealt shot-fastest: with a multiple of 8 shots every block of a shot carries the
 // same id modulo 8, i.e. runs on one XCD, whose L2 then holds that shot's working set.
 //
-// Equations: see kernels_generic.hip (same update, same gradient and illumination terms).
+// Equations: see kernels_generic.hip (same update and illumination term).  The gradient is the same
+// sum rearranged by parts over time,
+//     sum_t (u[t-1] - 2u[t] + u[t+1]) v[t]  =  sum_t u[t] (v[t+1] - 2v[t] + v[t-1]),
+// which is exact because u[0] = u[1] = 0 and the backward field starts from zero: no boundary
+// terms survive.  v[t-1] is the value this step produces, injected receiver term included.
 #include "mifwi_internal.hpp"
 
 namespace mifwi {
@@ -87,7 +91,7 @@ __global__ __launch_bounds__(256) void step2d_kernel(Step2DArgs a)
             stage[i] = *reinterpret_cast<const float4 *>(cur + (long)gx * a.s1 + (z0 - RZ + 4 * q));
     }
     float4 m4 = make_float4(1.f, 1.f, 1.f, 1.f), e4 = make_float4(0.f, 0.f, 0.f, 0.f), o4 = e4;
-    float4 um4 = e4, u04 = e4, up4 = e4, gv = e4, iv = e4;
+    float4 u04 = e4, up4 = e4, gv = e4, iv = e4;
     const long qs = (long)shot * a.u_shot_stride + p;
     const long gs = (long)shot * a.g_shot_stride + p;
     if (live) {
@@ -95,9 +99,8 @@ __global__ __launch_bounds__(256) void step2d_kernel(Step2DArgs a)
         e4 = *reinterpret_cast<const float4 *>(a.eta + p);
         o4 = *reinterpret_cast<const float4 *>(a.old + ps);
         if (GRAD) {
-            um4 = *reinterpret_cast<const float4 *>(a.um + qs);
             u04 = *reinterpret_cast<const float4 *>(a.uc + qs);
-            up4 = *reinterpret_cast<const float4 *>(a.up + qs);
+            if (a.first && a.illum) up4 = *reinterpret_cast<const float4 *>(a.up + qs);
             gv = *reinterpret_cast<const float4 *>(a.grad + gs);
             if (a.illum) iv = *reinterpret_cast<const float4 *>(a.illum + gs);
         }
@@ -179,13 +182,15 @@ __global__ __launch_bounds__(256) void step2d_kernel(Step2DArgs a)
                 if (z + i < a.n2) a.out[ps + i] = res[i];
         }
         if (GRAD) {
-            const float um[4] = {um4.x, um4.y, um4.z, um4.w}, u0[4] = {u04.x, u04.y, u04.z, u04.w},
-                        up[4] = {up4.x, up4.y, up4.z, up4.w};
+            const float u0[4] = {u04.x, u04.y, u04.z, u04.w}, up[4] = {up4.x, up4.y, up4.z, up4.w};
             float g[4] = {gv.x, gv.y, gv.z, gv.w}, il[4] = {iv.x, iv.y, iv.z, iv.w};
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                g[i] += -((um[i] - 2.0f * u0[i] + up[i]) * a.inv_dt2) * uc[i];
-                il[i] += u0[i] * u0[i] + (a.first ? up[i] * up[i] : 0.0f);
+                // zero-lag correlation, summed by parts over time: the second time difference is taken
+                // of the backward field (all three levels are in registers here) instead of the saved
+                // forward field, so one saved level is read per step instead of three
+                g[i] += -((oo[i] - 2.0f * uc[i] + res[i]) * a.inv_dt2) * u0[i];
+                il[i] += u0[i] * u0[i] + up[i] * up[i];
             }
             if (full) {
                 *reinterpret_cast<float4 *>(a.grad + gs) = make_float4(g[0], g[1], g[2], g[3]);
