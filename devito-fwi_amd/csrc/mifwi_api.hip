@@ -148,6 +148,8 @@ static void destroy(Plan *p)
     dev_free(p->rot_u);
     dev_free(p->rot_v);
     dev_free(p->saved);
+    dev_free(p->ckpt);
+    dev_free(p->seg);
     free_sparse(p->src);
     free_sparse(p->rec);
     dev_free(p->d_wavelet);
@@ -700,56 +702,232 @@ static void set_interp3(Step3DArgs &a, const SparseSet &S, void *vals_out)
     a.vals_out = (float *)vals_out;
 }
 
-// Run one time loop (`enqueue` launches its kernels on p.stream and counts them) bracketed by the
-// plan's events.  Unless MIFWI_FLAG_NO_GRAPH is set the loop is captured once into a HIP graph,
-// keyed by everything that changes its launches, and replayed afterwards: the host then issues one
-// graph launch instead of nt-2 kernel launches, which is what keeps small 2-D grids from being
-// bound by the host's launch rate.
-template <typename F>
-static int run_group(Plan &p, std::tuple<int, int, int, int, int> key, hipStream_t st, int shot0, int nsh, F &&enqueue,
-                     int &launches)
+// ---- time loops ------------------------------------------------------------------------------
+// Everything a loop needs that does not change from step to step.
+template <typename T>
+struct LoopCtx {
+    int nshots;
+    StepConsts<T> k;   // generic kernels
+    Step2DArgs a2;     // tiled 2-D kernel (float only)
+    Step3DArgs a3;     // 2.5-D kernel (float only)
+};
+
+template <typename T>
+static LoopCtx<T> make_ctx(const Plan &p, int nshots, bool grad)
 {
-    int rc = MIFWI_OK;
-    launches = 0;
-    if (p.cfg.flags & MIFWI_FLAG_NO_GRAPH) return enqueue(st, shot0, nsh, launches);
-    auto it = p.graphs.find(key);
-    if (it == p.graphs.end()) {
-        hipGraph_t graph = nullptr;
-        MIFWI_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
-        rc = enqueue(st, shot0, nsh, launches);
-        hipError_t e = hipStreamEndCapture(st, &graph);
-        if (rc) {
-            if (graph) (void)hipGraphDestroy(graph);
-            return rc;
-        }
-        if (e != hipSuccess) return fail(MIFWI_EHIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
-        hipGraphExec_t exec = nullptr;
-        e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
-        (void)hipGraphDestroy(graph);
-        if (e != hipSuccess) return fail(MIFWI_EHIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(e));
-        it = p.graphs.emplace(key, std::make_pair(exec, launches)).first;
+    LoopCtx<T> c{};
+    c.nshots = nshots;
+    c.k = make_consts<T>(p);
+    if (p.kind == 1) c.a2 = base2d(p, nshots);
+    if (p.kind == 2) c.a3 = base3d(p, nshots, grad);
+    return c;
+}
+
+// One forward step: out = step(cur, old) + injected source term of `time`; with `interp` the
+// receivers sample `cur` into d_rec[time].
+template <typename T>
+static int forward_step(Plan &p, const LoopCtx<T> &c, const T *cur, const T *old, T *out, long shot_stride, int time,
+                        bool interp, int &launches)
+{
+    int rc;
+    if (p.kind == 1) {
+        Step2DArgs a = c.a2;
+        a.shot_stride = shot_stride;
+        set_inject(a, p.src, p.d_wavelet);
+        if (interp) set_interp(a, p.rec, p.d_rec);
+        a.cur = (const float *)cur, a.old = (const float *)old, a.out = (float *)out, a.time = time;
+        if ((rc = launch_step2d(p, a, p.stream))) return rc;
+        launches += 1;
+        return MIFWI_OK;
     }
-    launches = it->second.second;
-    MIFWI_HIP(hipGraphLaunch(it->second.first, st));
+    if (p.kind == 2) {
+        Step3DArgs a = c.a3;
+        a.shot_stride = shot_stride;
+        set_inject3(a, p.src, p.d_wavelet);
+        if (interp) set_interp3(a, p.rec, p.d_rec);
+        a.cur = (const float *)cur, a.old = (const float *)old, a.out = (float *)out, a.time = time;
+        if ((rc = launch_step3d(p, a, p.stream))) return rc;
+        launches += 1;
+        return MIFWI_OK;
+    }
+    StepPtrs<T> sp{cur, old, out, shot_stride, (const T *)p.m, (const T *)p.eta};
+    GradPtrs<T> gp{};
+    if ((rc = launch_step_generic<T>(p, c.k, sp, gp, c.nshots))) return rc;
+    SparsePtrs<T> q{};
+    q.inj = &p.src;
+    q.field_inj = out;
+    q.vals_inj = (const T *)p.d_wavelet;
+    if (interp) {
+        q.itp = &p.rec;
+        q.field_int = cur;
+        q.vals_out = (T *)p.d_rec;
+    }
+    q.shot_stride = shot_stride;
+    q.m = (const T *)p.m;
+    q.time = time;
+    q.nt = p.cfg.nt;
+    q.dt2 = c.k.dt2;
+    if ((rc = launch_sparse<T>(p, q, c.nshots))) return rc;
+    launches += 2;
     return MIFWI_OK;
 }
 
-// `enqueue(stream, shot0, nsh, launches)` launches the loop for shots shot0..shot0+nsh-1.
+// One backward step: out = step(cur, old) + injected adjoint source of `time`.  With u0 != null
+// the gradient (and illumination) accumulators are updated from the saved forward levels
+// um/u0/up = u[time-1], u[time], u[time+1]; without, the field is sampled at the source positions.
+template <typename T>
+static int backward_step(Plan &p, const LoopCtx<T> &c, const T *cur, const T *old, T *out, long shot_stride, int time,
+                         const T *um, const T *u0, const T *up, long u_stride, bool with_illum, bool first,
+                         int &launches)
+{
+    int rc;
+    const bool with_grad = (u0 != nullptr);
+    if (p.kind == 1) {
+        Step2DArgs a = c.a2;
+        a.shot_stride = shot_stride;
+        set_inject(a, p.rec, p.d_res);
+        if (!with_grad) set_interp(a, p.src, p.d_srca);
+        a.cur = (const float *)cur, a.old = (const float *)old, a.out = (float *)out, a.time = time;
+        if (with_grad) {
+            a.um = (const float *)um, a.uc = (const float *)u0, a.up = (const float *)up;
+            a.u_shot_stride = u_stride;
+            a.grad = (float *)p.d_grad;
+            a.illum = with_illum ? (float *)p.d_illum : nullptr;
+            a.g_shot_stride = p.L.field;
+            a.first = first;
+        }
+        if ((rc = launch_step2d(p, a, p.stream))) return rc;
+        launches += 1;
+        return MIFWI_OK;
+    }
+    if (p.kind == 2) {
+        Step3DArgs a = c.a3;
+        a.shot_stride = shot_stride;
+        set_inject3(a, p.rec, p.d_res);
+        if (!with_grad) set_interp3(a, p.src, p.d_srca);
+        a.cur = (const float *)cur, a.old = (const float *)old, a.out = (float *)out, a.time = time;
+        if (with_grad) {
+            a.um = (const float *)um, a.uc = (const float *)u0, a.up = (const float *)up;
+            a.u_shot_stride = u_stride;
+            a.grad = (float *)p.d_grad;
+            a.illum = with_illum ? (float *)p.d_illum : nullptr;
+            a.g_shot_stride = p.L.field;
+            a.first = first;
+        }
+        if ((rc = launch_step3d(p, a, p.stream))) return rc;
+        launches += 1;
+        return MIFWI_OK;
+    }
+    StepPtrs<T> sp{cur, old, out, shot_stride, (const T *)p.m, (const T *)p.eta};
+    GradPtrs<T> gp{};
+    if (with_grad) {
+        gp.um = um, gp.uc = u0, gp.up = up;
+        gp.u_shot_stride = u_stride;
+        gp.grad = (T *)p.d_grad;
+        gp.illum = with_illum ? (T *)p.d_illum : nullptr;
+        gp.g_shot_stride = p.L.field;
+        gp.first = first;
+    }
+    if ((rc = launch_step_generic<T>(p, c.k, sp, gp, c.nshots))) return rc;
+    SparsePtrs<T> q{};
+    q.inj = &p.rec;
+    q.field_inj = out;
+    q.vals_inj = (const T *)p.d_res;
+    if (!with_grad) {
+        q.itp = &p.src;
+        q.field_int = cur;
+        q.vals_out = (T *)p.d_srca;
+    }
+    q.shot_stride = shot_stride;
+    q.m = (const T *)p.m;
+    q.time = time;
+    q.nt = p.cfg.nt;
+    q.dt2 = c.k.dt2;
+    if ((rc = launch_sparse<T>(p, q, c.nshots))) return rc;
+    launches += 2;
+    return MIFWI_OK;
+}
+
+// Run one time loop (`enqueue(launches)` launches its kernels on p.stream) bracketed by the plan's
+// events.  With `key` the loop is captured once into a HIP graph, keyed by everything that changes
+// its launches, and replayed afterwards: the host then issues one graph launch instead of nt-2
+// kernel launches, which keeps small 2-D grids from being bound by the host's launch rate.
 // (Splitting the batch into shot groups on separate streams was measured and rejected: chains on
 // different hardware queues did not overlap on MI355X, 8 shots in 2/4/8 groups ran 1.2-3x slower
 // than one chain.)
 template <typename F>
-static int timed_loop(Plan &p, std::tuple<int, int, int, int> key, int nshots, F &&enqueue, int &launches, float &ms)
+static int timed_loop(Plan &p, const std::tuple<int, int, int, int, int> *key, F &&enqueue, int &launches, float &ms)
 {
     int rc = MIFWI_OK;
     launches = 0;
     MIFWI_HIP(hipEventRecord(p.ev0, p.stream));
-    auto k5 = std::make_tuple(std::get<0>(key), std::get<1>(key), std::get<2>(key), std::get<3>(key), 0);
-    if ((rc = run_group(p, k5, p.stream, 0, nshots, enqueue, launches))) return rc;
+    if (!key || (p.cfg.flags & MIFWI_FLAG_NO_GRAPH)) {
+        if ((rc = enqueue(launches))) return rc;
+    } else {
+        auto it = p.graphs.find(*key);
+        if (it == p.graphs.end()) {
+            hipGraph_t graph = nullptr;
+            MIFWI_HIP(hipStreamBeginCapture(p.stream, hipStreamCaptureModeThreadLocal));
+            rc = enqueue(launches);
+            hipError_t e = hipStreamEndCapture(p.stream, &graph);
+            if (rc) {
+                if (graph) (void)hipGraphDestroy(graph);
+                return rc;
+            }
+            if (e != hipSuccess) return fail(MIFWI_EHIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
+            hipGraphExec_t exec = nullptr;
+            e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+            (void)hipGraphDestroy(graph);
+            if (e != hipSuccess) return fail(MIFWI_EHIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(e));
+            it = p.graphs.emplace(*key, std::make_pair(exec, launches)).first;
+            // the capture only recorded the loop; it has not run yet
+        }
+        launches = it->second.second;
+        MIFWI_HIP(hipGraphLaunch(it->second.first, p.stream));
+    }
     MIFWI_HIP(hipEventRecord(p.ev1, p.stream));
     MIFWI_HIP(hipEventSynchronize(p.ev1));
     MIFWI_HIP(hipEventElapsedTime(&ms, p.ev0, p.ev1));
     return MIFWI_OK;
+}
+
+// copy `nlev` consecutive levels of every shot between two [shot][levels][field] arrays
+template <typename T>
+static int copy_levels(Plan &p, T *dst, long dst_stride, const T *src, long src_stride, int nlev, int nshots)
+{
+    MIFWI_HIP(hipMemcpy2DAsync(dst, (size_t)dst_stride * sizeof(T), src, (size_t)src_stride * sizeof(T),
+                               (size_t)nlev * p.L.field * sizeof(T), (size_t)nshots, hipMemcpyDeviceToDevice, p.stream));
+    return MIFWI_OK;
+}
+
+// Decide, on the first saving forward run, how the forward wavefield is kept for the gradient:
+// every level (ck_K = 0) when that fits in free device memory, else two-level checkpointing:
+// the levels entering every ck_K-th step are kept and each segment is recomputed into a segment
+// buffer right before the backward pass crosses it.  The gradient is bit-identical either way
+// (same kernels, same order); the price is one more forward sweep.
+template <typename T>
+static int prepare_save(Plan &p)
+{
+    if (p.saved || p.ckpt) return MIFWI_OK;
+    const int nt = p.cfg.nt;
+    const size_t level = (size_t)p.cfg.max_shots * p.L.field * sizeof(T);
+    size_t free_b = 0, total_b = 0;
+    MIFWI_HIP(hipMemGetInfo(&free_b, &total_b));
+    const bool force = (p.cfg.flags & MIFWI_FLAG_CHECKPOINT) != 0;
+    int rc;
+    if (!force && (double)level * nt <= 0.85 * (double)free_b) {
+        p.ck_K = 0;
+        return dev_alloc(p, &p.saved, level * nt, true);
+    }
+    const int nsteps = nt - 2;
+    p.ck_K = std::max(2, (int)std::ceil(std::sqrt(2.0 * nsteps)));
+    p.ck_nseg = (nsteps + p.ck_K - 1) / p.ck_K;
+    const size_t need = level * (2 * (size_t)p.ck_nseg + p.ck_K + 2);
+    if ((double)need > 0.95 * (double)free_b)
+        return fail(MIFWI_ENOMEM, "not enough device memory even for the checkpointed wavefield (" +
+                                      std::to_string(need >> 20) + " MiB needed)");
+    if ((rc = dev_alloc(p, &p.ckpt, level * 2 * p.ck_nseg, true))) return rc;
+    return dev_alloc(p, &p.seg, level * (p.ck_K + 2), true);
 }
 
 // forward time loop on data already resident on the device (d_wavelet -> d_rec)
@@ -759,88 +937,52 @@ static int run_forward(Plan &p, int nshots, int save)
     const Layout &L = p.L;
     const int nt = p.cfg.nt;
     int rc;
+    if (save && (rc = prepare_save<T>(p))) return rc;
+    const bool full_save = save && p.ck_K == 0;
     T *base;
     long shot_stride;
-    if (save) {
-        if (!p.saved) {
-            const size_t bytes = (size_t)p.cfg.max_shots * nt * L.field * sizeof(T);
-            if ((rc = dev_alloc(p, &p.saved, bytes, true))) return rc;
-        }
+    if (full_save) {
         base = (T *)p.saved;
         shot_stride = (long)nt * L.field;
         for (int s = 0; s < nshots; ++s)  // u[0] = u[1] = 0
             MIFWI_HIP(hipMemsetAsync(base + s * shot_stride, 0, 2 * L.field * sizeof(T), p.stream));
-        p.saved_valid = false;
     } else {
         base = (T *)p.rot_u;
         shot_stride = 3L * L.field;
         MIFWI_HIP(hipMemsetAsync(base, 0, (size_t)nshots * shot_stride * sizeof(T), p.stream));
         p.rot_u_valid = false;
     }
+    if (save) p.saved_valid = false;
     MIFWI_HIP(hipMemsetAsync(p.d_rec, 0, (size_t)nshots * nt * p.cfg.nrec * sizeof(T), p.stream));
-    const StepConsts<T> k = make_consts<T>(p);
-    auto lvl = [&](int t) { return base + (long)(save ? t : t % 3) * L.field; };
-    auto enqueue = [&](hipStream_t st, int shot0, int nsh, int &launches) -> int {
-    if (p.kind == 1) {
-        Step2DArgs a = base2d(p, nsh);
-        a.shot0 = shot0;
-        a.shot_stride = shot_stride;
-        set_inject(a, p.src, p.d_wavelet);
-        set_interp(a, p.rec, p.d_rec);
+    const LoopCtx<T> ctx = make_ctx<T>(p, nshots, false);
+    auto lvl = [&](int t) { return base + (long)(full_save ? t : t % 3) * L.field; };
+    const bool ckpt = save && !full_save;
+    auto enqueue = [&](int &launches) -> int {
         for (int time = 1; time <= nt - 2; ++time) {
-            a.cur = (const float *)lvl(time);
-            a.old = (const float *)lvl(time - 1);
-            a.out = (float *)lvl(time + 1);
-            a.time = time;
-            if ((rc = launch_step2d(p, a, st))) return rc;
-            ++launches;
+            if (ckpt && (time - 1) % p.ck_K == 0) {
+                // keep the two levels that enter this segment: u[time-1], u[time]
+                const int j = (time - 1) / p.ck_K;
+                T *dst = (T *)p.ckpt + (long)j * 2 * L.field;
+                const long cstride = (long)p.ck_nseg * 2 * L.field;
+                int r;
+                if ((r = copy_levels<T>(p, dst, cstride, lvl(time - 1), shot_stride, 1, nshots))) return r;
+                if ((r = copy_levels<T>(p, dst + L.field, cstride, lvl(time), shot_stride, 1, nshots))) return r;
+            }
+            int r = forward_step<T>(p, ctx, lvl(time), lvl(time - 1), lvl(time + 1), shot_stride, time, true, launches);
+            if (r) return r;
         }
-    }
-    if (p.kind == 2) {
-        Step3DArgs a = base3d(p, nsh, false);
-        a.shot_stride = shot_stride;
-        set_inject3(a, p.src, p.d_wavelet);
-        set_interp3(a, p.rec, p.d_rec);
-        for (int time = 1; time <= nt - 2; ++time) {
-            a.cur = (const float *)lvl(time);
-            a.old = (const float *)lvl(time - 1);
-            a.out = (float *)lvl(time + 1);
-            a.time = time;
-            if ((rc = launch_step3d(p, a, st))) return rc;
-            ++launches;
-        }
-    }
-    for (int time = 1; p.kind == 0 && time <= nt - 2; ++time) {
-        StepPtrs<T> sp{lvl(time), lvl(time - 1), lvl(time + 1), shot_stride, (const T *)p.m, (const T *)p.eta};
-        GradPtrs<T> gp{};
-        if ((rc = launch_step_generic<T>(p, k, sp, gp, nshots))) return rc;
-        SparsePtrs<T> q{};
-        q.inj = &p.src;
-        q.field_inj = lvl(time + 1);
-        q.vals_inj = (const T *)p.d_wavelet;
-        q.itp = &p.rec;
-        q.field_int = lvl(time);
-        q.vals_out = (T *)p.d_rec;
-        q.shot_stride = shot_stride;
-        q.m = (const T *)p.m;
-        q.time = time;
-        q.nt = nt;
-        q.dt2 = k.dt2;
-        if ((rc = launch_sparse<T>(p, q, nshots))) return rc;
-        launches += 2;
-    }
-    return MIFWI_OK;
+        return MIFWI_OK;
     };
     int launches = 0;
     float ms = 0;
-    if ((rc = timed_loop(p, std::make_tuple(0, nshots, save ? 1 : 0, 0), nshots, enqueue, launches, ms))) return rc;
+    const auto key = std::make_tuple(0, nshots, save ? 1 : 0, 0, 0);
+    if ((rc = timed_loop(p, ckpt ? nullptr : &key, enqueue, launches, ms))) return rc;
     fill_stats(p, ms, nt - 2, nshots, 20.0, launches, false);
     if (save) {
         p.saved_valid = true;
         p.saved_shots = nshots;
-    } else {
-        p.rot_u_valid = true;
     }
+    if (!full_save) p.rot_u_valid = true;
     return MIFWI_OK;
 }
 
@@ -869,97 +1011,52 @@ static int run_backward(Plan &p, int nshots, bool with_grad, bool with_illum)
     } else {
         MIFWI_HIP(hipMemsetAsync(p.d_srca, 0, (size_t)nshots * nt * p.cfg.nsrc * sizeof(T), p.stream));
     }
-    const StepConsts<T> k = make_consts<T>(p);
+    const LoopCtx<T> ctx = make_ctx<T>(p, nshots, with_grad);
+    const LoopCtx<T> fctx = make_ctx<T>(p, nshots, false);
     auto lvl = [&](int t) { return base + (long)((t + 3) % 3) * L.field; };
-    const T *sv = (const T *)p.saved;
-    const long sv_stride = (long)nt * L.field;
-    auto enqueue = [&](hipStream_t st, int shot0, int nsh, int &launches) -> int {
-    if (p.kind == 1) {
-        Step2DArgs a = base2d(p, nsh);
-        a.shot0 = shot0;
-        a.shot_stride = shot_stride;
-        set_inject(a, p.rec, p.d_res);
-        if (!with_grad) set_interp(a, p.src, p.d_srca);
-        for (int time = nt - 2; time >= 1; --time) {
-            a.cur = (const float *)lvl(time);
-            a.old = (const float *)lvl(time + 1);
-            a.out = (float *)lvl(time - 1);
-            a.time = time;
-            if (with_grad) {
-                a.um = (const float *)sv + (long)(time - 1) * L.field;
-                a.uc = (const float *)sv + (long)time * L.field;
-                a.up = (const float *)sv + (long)(time + 1) * L.field;
-                a.u_shot_stride = sv_stride;
-                a.grad = (float *)p.d_grad;
-                a.illum = with_illum ? (float *)p.d_illum : nullptr;
-                a.g_shot_stride = L.field;
-                a.first = (time == nt - 2);
+    const bool ckpt = with_grad && p.ck_K > 0;
+    auto enqueue = [&](int &launches) -> int {
+        int r;
+        if (!ckpt) {
+            const T *sv = (const T *)p.saved;
+            const long sv_stride = (long)nt * L.field;
+            for (int time = nt - 2; time >= 1; --time) {
+                const T *u0 = with_grad ? sv + (long)time * L.field : nullptr;
+                if ((r = backward_step<T>(p, ctx, lvl(time), lvl(time + 1), lvl(time - 1), shot_stride, time,
+                                          u0 ? u0 - L.field : nullptr, u0, u0 ? u0 + L.field : nullptr, sv_stride,
+                                          with_illum, time == nt - 2, launches)))
+                    return r;
             }
-            if ((rc = launch_step2d(p, a, st))) return rc;
-            ++launches;
+            return MIFWI_OK;
         }
-    }
-    if (p.kind == 2) {
-        Step3DArgs a = base3d(p, nsh, with_grad);
-        a.shot_stride = shot_stride;
-        set_inject3(a, p.rec, p.d_res);
-        if (!with_grad) set_interp3(a, p.src, p.d_srca);
-        for (int time = nt - 2; time >= 1; --time) {
-            a.cur = (const float *)lvl(time);
-            a.old = (const float *)lvl(time + 1);
-            a.out = (float *)lvl(time - 1);
-            a.time = time;
-            if (with_grad) {
-                a.um = (const float *)sv + (long)(time - 1) * L.field;
-                a.uc = (const float *)sv + (long)time * L.field;
-                a.up = (const float *)sv + (long)(time + 1) * L.field;
-                a.u_shot_stride = sv_stride;
-                a.grad = (float *)p.d_grad;
-                a.illum = with_illum ? (float *)p.d_illum : nullptr;
-                a.g_shot_stride = L.field;
-                a.first = (time == nt - 2);
+        // checkpointed: walk the segments backwards, recomputing each into the segment buffer first
+        T *seg = (T *)p.seg;
+        const long seg_stride = (long)(p.ck_K + 2) * L.field;
+        const long cstride = (long)p.ck_nseg * 2 * L.field;
+        for (int j = p.ck_nseg - 1; j >= 0; --j) {
+            const int t0 = 1 + j * p.ck_K, t1 = std::min(nt - 2, t0 + p.ck_K - 1);
+            // seg level i holds u[t0 - 1 + i]
+            if ((r = copy_levels<T>(p, seg, seg_stride, (const T *)p.ckpt + (long)j * 2 * L.field, cstride, 2, nshots)))
+                return r;
+            for (int time = t0; time <= t1; ++time) {
+                T *c = seg + (long)(time - t0 + 1) * L.field;
+                if ((r = forward_step<T>(p, fctx, c, c - L.field, c + L.field, seg_stride, time, false, launches)))
+                    return r;
             }
-            if ((rc = launch_step3d(p, a, st))) return rc;
-            ++launches;
+            for (int time = t1; time >= t0; --time) {
+                const T *u0 = seg + (long)(time - t0 + 1) * L.field;
+                if ((r = backward_step<T>(p, ctx, lvl(time), lvl(time + 1), lvl(time - 1), shot_stride, time,
+                                          u0 - L.field, u0, u0 + L.field, seg_stride, with_illum, time == nt - 2,
+                                          launches)))
+                    return r;
+            }
         }
-    }
-    for (int time = nt - 2; p.kind == 0 && time >= 1; --time) {
-        StepPtrs<T> sp{lvl(time), lvl(time + 1), lvl(time - 1), shot_stride, (const T *)p.m, (const T *)p.eta};
-        GradPtrs<T> gp{};
-        if (with_grad) {
-            gp.um = sv + (long)(time - 1) * L.field;
-            gp.uc = sv + (long)time * L.field;
-            gp.up = sv + (long)(time + 1) * L.field;
-            gp.u_shot_stride = sv_stride;
-            gp.grad = (T *)p.d_grad;
-            gp.illum = with_illum ? (T *)p.d_illum : nullptr;
-            gp.g_shot_stride = L.field;
-            gp.first = (time == nt - 2);
-        }
-        if ((rc = launch_step_generic<T>(p, k, sp, gp, nshots))) return rc;
-        SparsePtrs<T> q{};
-        q.inj = &p.rec;
-        q.field_inj = lvl(time - 1);
-        q.vals_inj = (const T *)p.d_res;
-        if (!with_grad) {
-            q.itp = &p.src;
-            q.field_int = lvl(time);
-            q.vals_out = (T *)p.d_srca;
-        }
-        q.shot_stride = shot_stride;
-        q.m = (const T *)p.m;
-        q.time = time;
-        q.nt = nt;
-        q.dt2 = k.dt2;
-        if ((rc = launch_sparse<T>(p, q, nshots))) return rc;
-        launches += 2;
-    }
-    return MIFWI_OK;
+        return MIFWI_OK;
     };
     int launches = 0;
     float ms = 0;
-    if ((rc = timed_loop(p, std::make_tuple(1, nshots, with_grad ? 1 : 0, with_illum ? 1 : 0), nshots, enqueue, launches, ms)))
-        return rc;
+    const auto key = std::make_tuple(1, nshots, with_grad ? 1 : 0, with_illum ? 1 : 0, 0);
+    if ((rc = timed_loop(p, ckpt ? nullptr : &key, enqueue, launches, ms))) return rc;
     fill_stats(p, ms, nt - 2, nshots, with_grad ? 32.0 : 20.0, launches, true);
     p.rot_v_valid = true;
     return MIFWI_OK;
@@ -1064,6 +1161,7 @@ static int read_wavefield(Plan &p, int which, int shot, int first, int count, vo
     int nlev;
     if (which == 0) {
         if (!p.saved_valid || shot >= p.saved_shots) return fail(MIFWI_ESTATE, "no saved wavefield for this shot");
+        if (p.ck_K > 0) return fail(MIFWI_ESTATE, "the forward wavefield is checkpointed, not stored level by level");
         base = (const T *)p.saved + (long)shot * p.cfg.nt * p.L.field;
         nlev = p.cfg.nt;
     } else if (which == 1 || which == 2) {
@@ -1099,10 +1197,8 @@ static int write_wavefield(Plan &p, int shot, int first, int count, const void *
     if (shot < 0 || shot >= p.cfg.max_shots) return fail(MIFWI_EINVAL, "shot out of range");
     if (first < 0 || count < 0 || first + count > p.cfg.nt) return fail(MIFWI_EINVAL, "level range out of bounds");
     int rc;
-    if (!p.saved) {
-        const size_t bytes = (size_t)p.cfg.max_shots * p.cfg.nt * p.L.field * sizeof(T);
-        if ((rc = dev_alloc(p, &p.saved, bytes, true))) return rc;
-    }
+    if ((rc = prepare_save<T>(p))) return rc;
+    if (p.ck_K > 0) return fail(MIFWI_ESTATE, "a caller-provided wavefield needs level-by-level storage, which does not fit");
     T *base = (T *)p.saved + (long)shot * p.cfg.nt * p.L.field;
     const bool dev = is_device_ptr(in);
     const int chunk = dev ? count : (int)std::max<size_t>(1, p.dense_elems / (size_t)p.L.ngrid);
