@@ -35,6 +35,26 @@ __device__ inline float fast_div(float a, float b)
     return __builtin_fmaf(__builtin_fmaf(-b, q, a), r, q);
 }
 
+typedef float vfloat4_2d __attribute__((ext_vector_type(4)));
+__device__ inline void st4_out(float *p, float4 v)
+{
+#ifdef MIFWI_2D_NT_STORE
+    vfloat4_2d t = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(t, reinterpret_cast<vfloat4_2d *>(p));
+#else
+    *reinterpret_cast<float4 *>(p) = v;
+#endif
+}
+__device__ inline float4 ld4_saved(const float *p)
+{
+#ifdef MIFWI_2D_NT_LOAD
+    const vfloat4_2d v = __builtin_nontemporal_load(reinterpret_cast<const vfloat4_2d *>(p));
+    return make_float4(v.x, v.y, v.z, v.w);
+#else
+    return *reinterpret_cast<const float4 *>(p);
+#endif
+}
+
 template <int R, int TX, int TZ, bool GRAD>
 __global__ __launch_bounds__(256) void step2d_kernel(Step2DArgs a)
 {
@@ -99,7 +119,7 @@ __global__ __launch_bounds__(256) void step2d_kernel(Step2DArgs a)
         e4 = *reinterpret_cast<const float4 *>(a.eta + p);
         o4 = *reinterpret_cast<const float4 *>(a.old + ps);
         if (GRAD) {
-            u04 = *reinterpret_cast<const float4 *>(a.uc + qs);
+            u04 = ld4_saved(a.uc + qs);
             if (a.first && a.illum) up4 = *reinterpret_cast<const float4 *>(a.up + qs);
             gv = *reinterpret_cast<const float4 *>(a.grad + gs);
             if (a.illum) iv = *reinterpret_cast<const float4 *>(a.illum + gs);
@@ -176,7 +196,7 @@ __global__ __launch_bounds__(256) void step2d_kernel(Step2DArgs a)
         }
         const bool full = (z + 3 < a.n2);
         if (full) {
-            *reinterpret_cast<float4 *>(a.out + ps) = make_float4(res[0], res[1], res[2], res[3]);
+            st4_out(a.out + ps, make_float4(res[0], res[1], res[2], res[3]));
         } else {
             for (int i = 0; i < 4; ++i)
                 if (z + i < a.n2) a.out[ps + i] = res[i];

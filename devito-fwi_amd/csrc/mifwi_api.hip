@@ -942,10 +942,11 @@ static int run_forward(Plan &p, int nshots, int save)
     T *base;
     long shot_stride;
     if (full_save) {
+        // saved field is level-major, [nt][max_shots][field]: one step reads and writes one
+        // contiguous run of memory for the whole batch
         base = (T *)p.saved;
-        shot_stride = (long)nt * L.field;
-        for (int s = 0; s < nshots; ++s)  // u[0] = u[1] = 0
-            MIFWI_HIP(hipMemsetAsync(base + s * shot_stride, 0, 2 * L.field * sizeof(T), p.stream));
+        shot_stride = L.field;
+        MIFWI_HIP(hipMemsetAsync(base, 0, 2 * (size_t)p.cfg.max_shots * L.field * sizeof(T), p.stream));  // u[0] = u[1] = 0
     } else {
         base = (T *)p.rot_u;
         shot_stride = 3L * L.field;
@@ -955,7 +956,8 @@ static int run_forward(Plan &p, int nshots, int save)
     if (save) p.saved_valid = false;
     MIFWI_HIP(hipMemsetAsync(p.d_rec, 0, (size_t)nshots * nt * p.cfg.nrec * sizeof(T), p.stream));
     const LoopCtx<T> ctx = make_ctx<T>(p, nshots, false);
-    auto lvl = [&](int t) { return base + (long)(full_save ? t : t % 3) * L.field; };
+    const long sv_lstride = (long)p.cfg.max_shots * L.field;
+    auto lvl = [&](int t) { return full_save ? base + (long)t * sv_lstride : base + (long)(t % 3) * L.field; };
     const bool ckpt = save && !full_save;
     auto enqueue = [&](int &launches) -> int {
         for (int time = 1; time <= nt - 2; ++time) {
@@ -1019,11 +1021,11 @@ static int run_backward(Plan &p, int nshots, bool with_grad, bool with_illum)
         int r;
         if (!ckpt) {
             const T *sv = (const T *)p.saved;
-            const long sv_stride = (long)nt * L.field;
+            const long sv_lstride = (long)p.cfg.max_shots * L.field, sv_stride = L.field;
             for (int time = nt - 2; time >= 1; --time) {
-                const T *u0 = with_grad ? sv + (long)time * L.field : nullptr;
+                const T *u0 = with_grad ? sv + (long)time * sv_lstride : nullptr;
                 if ((r = backward_step<T>(p, ctx, lvl(time), lvl(time + 1), lvl(time - 1), shot_stride, time,
-                                          u0 ? u0 - L.field : nullptr, u0, u0 ? u0 + L.field : nullptr, sv_stride,
+                                          u0 ? u0 - sv_lstride : nullptr, u0, u0 ? u0 + sv_lstride : nullptr, sv_stride,
                                           with_illum, time == nt - 2, launches)))
                     return r;
             }
@@ -1159,10 +1161,12 @@ static int read_wavefield(Plan &p, int which, int shot, int first, int count, vo
     if (shot < 0 || shot >= p.cfg.max_shots) return fail(MIFWI_EINVAL, "shot out of range");
     const T *base;
     int nlev;
+    long lstride = p.L.field;   // elements between consecutive levels of one shot
     if (which == 0) {
         if (!p.saved_valid || shot >= p.saved_shots) return fail(MIFWI_ESTATE, "no saved wavefield for this shot");
         if (p.ck_K > 0) return fail(MIFWI_ESTATE, "the forward wavefield is checkpointed, not stored level by level");
-        base = (const T *)p.saved + (long)shot * p.cfg.nt * p.L.field;
+        base = (const T *)p.saved + (long)shot * p.L.field;
+        lstride = (long)p.cfg.max_shots * p.L.field;
         nlev = p.cfg.nt;
     } else if (which == 1 || which == 2) {
         if (!(which == 1 ? p.rot_u_valid : p.rot_v_valid)) return fail(MIFWI_ESTATE, "no buffered wavefield available");
@@ -1174,15 +1178,15 @@ static int read_wavefield(Plan &p, int which, int shot, int first, int count, vo
     if (first < 0 || count < 0 || first + count > nlev) return fail(MIFWI_EINVAL, "level range out of bounds");
     int rc;
     const bool dev = is_device_ptr(out);
-    // levels are consecutive fields: treat them as `count` "shots" of one level each
+    // levels are evenly spaced fields: treat them as `count` "shots" of one level each
     const int chunk = dev ? count : (int)std::max<size_t>(1, p.dense_elems / (size_t)p.L.ngrid);
     for (int l = 0; l < count; l += chunk) {
         const int n = std::min(chunk, count - l);
         T *dst = (T *)out + (long)l * p.L.ngrid;
         if (dev) {
-            if ((rc = launch_unpack<T>(p, base + (long)(first + l) * p.L.field, p.L.field, dst, n, 0))) return rc;
+            if ((rc = launch_unpack<T>(p, base + (long)(first + l) * lstride, lstride, dst, n, 0))) return rc;
         } else {
-            if ((rc = launch_unpack<T>(p, base + (long)(first + l) * p.L.field, p.L.field, (T *)p.d_dense, n, 0))) return rc;
+            if ((rc = launch_unpack<T>(p, base + (long)(first + l) * lstride, lstride, (T *)p.d_dense, n, 0))) return rc;
             if ((rc = copy_any(p, dst, p.d_dense, (size_t)n * p.L.ngrid * sizeof(T)))) return rc;
             MIFWI_HIP(hipStreamSynchronize(p.stream));
         }
@@ -1199,7 +1203,8 @@ static int write_wavefield(Plan &p, int shot, int first, int count, const void *
     int rc;
     if ((rc = prepare_save<T>(p))) return rc;
     if (p.ck_K > 0) return fail(MIFWI_ESTATE, "a caller-provided wavefield needs level-by-level storage, which does not fit");
-    T *base = (T *)p.saved + (long)shot * p.cfg.nt * p.L.field;
+    T *base = (T *)p.saved + (long)shot * p.L.field;
+    const long lstride = (long)p.cfg.max_shots * p.L.field;
     const bool dev = is_device_ptr(in);
     const int chunk = dev ? count : (int)std::max<size_t>(1, p.dense_elems / (size_t)p.L.ngrid);
     for (int l = 0; l < count; l += chunk) {
@@ -1209,7 +1214,7 @@ static int write_wavefield(Plan &p, int shot, int first, int count, const void *
             if ((rc = copy_any(p, p.d_dense, src, (size_t)n * p.L.ngrid * sizeof(T)))) return rc;
             src = (const T *)p.d_dense;
         }
-        if ((rc = launch_pack<T>(p, src, base + (long)(first + l) * p.L.field, p.L.field, n))) return rc;
+        if ((rc = launch_pack<T>(p, src, base + (long)(first + l) * lstride, lstride, n))) return rc;
         if (!dev) MIFWI_HIP(hipStreamSynchronize(p.stream));
     }
     // a caller-provided field makes the shot usable by mifwi_gradient

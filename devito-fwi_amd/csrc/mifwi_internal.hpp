@@ -102,7 +102,7 @@ struct Plan {
 
     void *rot_u = nullptr;                   // [max_shots][3][field] forward rotating buffers
     void *rot_v = nullptr;                   // [max_shots][3][field] adjoint rotating buffers
-    void *saved = nullptr;                   // [max_shots][nt][field] saved forward field
+    void *saved = nullptr;                   // [nt][max_shots][field] saved forward field (level-major)
     void *ckpt = nullptr;                    // [max_shots][ck_nseg][2][field] levels entering each segment
     void *seg = nullptr;                     // [max_shots][ck_K+2][field] recomputed segment
     int ck_K = 0, ck_nseg = 0;               // segment length (0: every level is stored) and count
