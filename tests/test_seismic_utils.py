@@ -119,3 +119,39 @@ def test_update_repads_and_m():
     np.testing.assert_allclose(model.m, 1 / model.vp.data ** 2)
     with pytest.raises(ValueError):
         model.update('vp', np.ones((5, 5)))
+
+
+def test_qwasserstein_1d_closed_forms():
+    """Shifted positive bumps: W2^2/2 = shift^2/2 in normalised time; identical signals: zero
+    loss and zero adjoint source; the adjoint source correlates with the finite-difference
+    derivative (the reference's expression, misfit/misfit.py:64-68, is a scaled approximation)."""
+    from misfit import qWasserstein, least_square, Misfit
+    n = 801
+    t = np.linspace(0, 1, n)
+
+    def bump(c):
+        return np.exp(-0.5 * ((t - c) / 0.03) ** 2)
+    w = qWasserstein(trans_type='none', method='1d')
+    loss, adj = w(bump(0.4), bump(0.55))
+    assert loss == pytest.approx(0.5 * 0.15 ** 2, rel=2e-3)
+    loss0, adj0 = w(bump(0.4) + 0.05, bump(0.4) + 0.05)     # strictly increasing CDFs
+    assert loss0 == pytest.approx(0, abs=1e-12) and np.abs(adj0).max() < 1e-9
+    # gathers: column-wise sum, shape preserved, 'linear' makes signed data positive
+    wl = qWasserstein(trans_type='linear', gamma=1.01, method='1d')
+    f = np.stack([bump(0.3) - 0.2 * bump(0.5), bump(0.6) - 0.1 * bump(0.2)], axis=1)
+    g = np.stack([bump(0.35) - 0.2 * bump(0.55), bump(0.5) - 0.1 * bump(0.1)], axis=1)
+    loss2, adj2 = wl(f, g)
+    assert adj2.shape == f.shape and loss2 > 0
+    eps, fd = 1e-6, np.zeros(40)
+    idx = np.linspace(100, 700, 40).astype(int)
+    for k, i in enumerate(idx):
+        fp, fm = f.copy(), f.copy()
+        fp[i, 0] += eps
+        fm[i, 0] -= eps
+        fd[k] = (wl(fp, g)[0] - wl(fm, g)[0]) / (2 * eps)
+    # the shift constant depends on min(f, g) only, so the perturbation leaves it unchanged
+    corr = np.corrcoef(fd, adj2[idx, 0])[0, 1]
+    assert corr > 0.9
+    with pytest.raises(NotImplementedError):
+        qWasserstein(method='2d')
+    assert Misfit(least_square)(np.ones(3), np.zeros(3))[0] == pytest.approx(1.5)
