@@ -128,6 +128,35 @@ def roofline_3d(mifwi, device, space_order=16, n=512, nbl=40, nt=14):
                         % (n, nbl, sp[0], space_order)}
 
 
+def fwi_iteration(true_model, init_model, src_all, rec, k=3, reps=3):
+    """Wall time of one FWI iteration through the drop-in Python API (fwi.fwi_loss): one
+    objective+gradient evaluation followed by k forward-only line-search evaluations, all shots of
+    the survey sharded over the ranks.  Called on every rank; returns the per-iteration time."""
+    import torch
+    from seismic import AcquisitionGeometry
+    from fwi import fm_multi, fwi_loss
+    from misfit import least_square
+    from copy import deepcopy
+    init_model = deepcopy(init_model)            # fwi_loss writes trial velocities into the model
+    g_true = AcquisitionGeometry(true_model, rec, src_all, 0., 4500., f0=0.007, src_type='Ricker')
+    g_init = AcquisitionGeometry(init_model, rec, src_all, 0., 4500., f0=0.007, src_type='Ricker')
+    obs = fm_multi(g_true)
+    mask = np.ones(init_model.shape, dtype=np.float32)
+    mask[:, :15] = 0
+    m0 = 1.0 / np.asarray(init_model.vp.data[init_model.nbl:-init_model.nbl,
+                                             init_model.nbl:-init_model.nbl], dtype=np.float64).reshape(-1) ** 2
+    fwi_loss(m0, g_init, obs, least_square, None, mask, True)                       # warm-up
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for r in range(reps):
+        f, g, _ = fwi_loss(m0, g_init, obs, least_square, None, mask, True)
+        p = -g * (0.01 * np.abs(m0).max() / np.abs(g).max())
+        for j in range(k):
+            fwi_loss(m0 + (j + 1) * p, g_init, obs, least_square, None, mask, True, calc_grad=False)
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / reps * 1e3, k, float(f)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -269,6 +298,15 @@ def main():
         "roofline": roofline, "roofline_forward": roofline_fwd,
     }
     plan.close()
+    it_ms, it_k, it_f = fwi_iteration(true_model, init_model, src_all, rec)
+    if world > 1:
+        t = torch.tensor([it_ms], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        it_ms = float(t.item())
+    out["fwi_iteration"] = {"ms": it_ms, "gradient_evaluations": 1, "forward_only_evaluations": it_k,
+                            "shots": nshots_total, "objective": it_f,
+                            "what": "fwi.fwi_loss through the Python API: model update, batched shots, "
+                                    "muting, preconditioner, mask, all-reduce"}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(true_model, init_model, src_all, rec, wavelet, dt, so)
     if rank == 0 and world == 1 and not args.no_3d:

@@ -19,7 +19,8 @@ from seismic.acoustic import AcousticWaveSolver
 from misfit import least_square
 
 __all__ = ['fm_single', 'fm_multi', 'fwi_obj_single', 'fwi_obj_multi', 'fwi_loss',
-           'fix_source_illumination', 'resample', 'Filter', 'seismic_filter', 'shot_partition']
+           'fix_source_illumination', 'resample', 'Filter', 'seismic_filter', 'shot_partition',
+           'clear_caches']
 
 
 # ---------------------------------------------------------------------------------------------
@@ -193,24 +194,113 @@ def _wavelet(geometry):
     return _shot_geometry(geometry, 0).src.data
 
 
+# Subtracting the direct wave from both synthetic and observed data (reference fwi.py:148-150)
+# leaves the least-squares residual and objective unchanged, so that case also takes the route
+# that forms the residual on the device.  Set to False to evaluate (syn - dw) - (obs - dw) on the
+# host in float32 exactly as the reference does.
+FUSE_DIRECT_WAVE = True
+
+_device_data = {}       # (plan id, ids of the shot arrays) -> (fingerprint, device tensor, arrays)
+_DEVICE_DATA_MAX = 4
+
+
+def clear_caches():
+    """Forget the device-resident copies of observed data."""
+    _device_data.clear()
+
+
+def _resident_batch(plan, objs, shots, dtype):
+    """(ns, nt, nrec) device tensor of objs[i].data for i in shots, uploaded once and reused for as
+    long as the same arrays are passed with unchanged content.  Content is watched through a
+    strided checksum, which notices refilled arrays but not single-sample edits: call
+    clear_caches() after editing observed data in place."""
+    import torch
+    arrays = [objs[i].data for i in shots]
+    key = (id(plan),) + tuple(id(a) for a in arrays)
+    finger = tuple(float(np.asarray(a).reshape(-1)[::251].sum(dtype=np.float64)) for a in arrays)
+    hit = _device_data.get(key)
+    if hit is not None and hit[0] == finger:
+        return hit[1]
+    dev = torch.as_tensor(np.stack(arrays).astype(dtype, copy=False)).to('cuda')
+    while len(_device_data) >= _DEVICE_DATA_MAX:
+        _device_data.pop(next(iter(_device_data)))
+    _device_data[key] = (finger, dev, arrays)
+    return dev
+
+
+class _DeviceResiduals(object):
+    """Residuals of one batch kept on the GPU and copied to the host on first access; behaves
+    like the (ns, nt, nrec) array it stands for."""
+
+    def __init__(self, tensor):
+        self._tensor = tensor
+        self._host = None
+
+    def _fetch(self):
+        if self._host is None:
+            self._host = self._tensor.cpu().numpy()
+            self._tensor = None
+        return self._host
+
+    def __getitem__(self, k):
+        return self._fetch()[k]
+
+    def __len__(self):
+        return len(self._fetch())
+
+    def __array__(self, dtype=None, copy=None):
+        a = self._fetch()
+        return a if dtype is None else a.astype(dtype)
+
+
+class _ResidualList(object):
+    """What fwi_obj_multi returns as `residuals`: indexable per shot like the reference's list of
+    (nt, nrec) arrays (fwi.py:184-189), fetching from the device only when an entry is read."""
+
+    def __init__(self, nsrc):
+        self._rows = [None] * nsrc
+
+    def _set(self, i, batch, k):
+        self._rows[i] = (batch, k)
+
+    def _set_array(self, i, arr):
+        self._rows[i] = arr
+
+    def __len__(self):
+        return len(self._rows)
+
+    def __getitem__(self, i):
+        row = self._rows[i]
+        if isinstance(row, tuple):
+            return row[0][row[1]]
+        return row
+
+    def __iter__(self):
+        return (self[i] for i in range(len(self)))
+
+
 def _compute_batch(geometry, shots, obs, direct_wave, misfit_func, calc_grad):
     """Objective pieces of the shots `shots` (indices into the survey) as one GPU batch:
     (fvals per shot, residuals (ns, nt, nrec), padded-grid gradients (ns, *grid) or None,
-    illumination likewise).  With the least-squares misfit and no direct wave the residual is
-    formed on the device; otherwise the misfit runs on the host between the two passes."""
+    illumination likewise).  With the least-squares misfit the residual is formed on the device
+    from device-resident observed data and stays there until somebody reads it; with any other
+    misfit function the misfit runs on the host between the two passes."""
     model = geometry.model
     entry = _batch_entry(geometry, shots)
     plan = entry.plan
     ns = len(shots)
     wavelet = _wavelet(geometry)
+    if misfit_func is least_square and (direct_wave is None or FUSE_DIRECT_WAVE):
+        import torch
+        obs_dev = _resident_batch(plan, obs, shots, model.dtype)
+        res_dev = torch.empty_like(obs_dev)
+        out = plan.l2_misfit_gradient(wavelet, obs_dev, nshots=ns, calc_grad=calc_grad, want_illum=True,
+                                      residual=res_dev)
+        return out['fval'], _DeviceResiduals(res_dev), out['grad'], out['illum']
     obs_b = np.stack([obs[i].data for i in shots]).astype(model.dtype, copy=False)
     dw_b = None
     if direct_wave is not None:
         dw_b = np.stack([direct_wave[i].data for i in shots]).astype(model.dtype, copy=False)
-    if misfit_func is least_square and dw_b is None:
-        out = plan.l2_misfit_gradient(wavelet, obs_b, nshots=ns, calc_grad=calc_grad, want_illum=True,
-                                      want_residual=True)
-        return out['fval'], out['residual'], out['grad'], out['illum']
     syn_b = plan.forward(wavelet, nshots=ns, save=calc_grad)
     res_b = np.empty_like(syn_b)
     fvals = []
@@ -311,7 +401,7 @@ def fwi_obj_multi(geometry, obs, misfit_func, direct_wave=None, mask=None, preco
     fval = .0
     grad = np.zeros(model.shape)
     illum = np.zeros(model.shape)
-    residuals = [None] * nsrc
+    residuals = _ResidualList(nsrc)
     if mine and not _same_sampling(geometry, [obs[i] for i in mine] +
                                    ([direct_wave[i] for i in mine] if direct_wave is not None else [])):
         # resampled data: shot-by-shot, as the reference does it
@@ -320,7 +410,7 @@ def fwi_obj_multi(geometry, obs, misfit_func, direct_wave=None, mask=None, preco
                                              direct_wave[i] if direct_wave is not None else None, geometry.dt,
                                              calc_grad)
             fval += f_
-            residuals[i] = r_
+            residuals._set_array(i, r_)
             if calc_grad:
                 grad += g_
                 illum += il_
@@ -329,7 +419,7 @@ def fwi_obj_multi(geometry, obs, misfit_func, direct_wave=None, mask=None, preco
         crop = tuple(slice(nbl, -nbl) if nbl else slice(None) for _ in range(model.dim))
         for k, i in enumerate(mine):
             fval += float(fvals[k])
-            residuals[i] = res_b[k]
+            residuals._set(i, res_b, k)
             if calc_grad:
                 mute = _mute_factor(model.shape, model.spacing, geometry.src_positions[i], geometry.rec_positions)
                 grad += g_b[k][crop] * mute

@@ -215,7 +215,8 @@ class Plan(object):
         return (grad, il) if pl is not None else grad
 
     def l2_misfit_gradient(self, wavelet, obs, nshots=None, wavelet_per_shot=False, calc_grad=True,
-                           grad=None, illum=None, want_illum=True, want_residual=False, want_syn=False, fval=None):
+                           grad=None, illum=None, want_illum=True, want_residual=False, want_syn=False, fval=None,
+                           residual=None):
         nshots = nshots or self.nshots
         pw, kw = self._in(wavelet)
         po, ko = self._in(obs)
@@ -228,8 +229,8 @@ class Plan(object):
                 pl, il = self._out(illum, (nshots,) + self.shape)
         else:
             grad = None
-        if want_residual:
-            pr, res = self._out(None, (nshots, self.nt, self.nrec))
+        if want_residual or residual is not None:
+            pr, res = self._out(residual, (nshots, self.nt, self.nrec))
         if want_syn:
             ps, syn = self._out(None, (nshots, self.nt, self.nrec))
         self._check(self._lib.mifwi_l2_misfit_gradient(self._h, nshots, pw, int(bool(wavelet_per_shot)), po, pf,
