@@ -344,6 +344,15 @@ __global__ __launch_bounds__(TY *TZ / V, (GRAD ? 2 : 3) * (TY * TZ / V) / 256) v
                 for (int i = 0; i < V; ++i)
                     if (z + i < a.n2) po[i] = res[i];
             }
+            if (a.fs && z <= R) {
+                // free surface: antisymmetric mirror of rows 1..R into the z halo (see kernels_tiled2d.hip)
+                float *po = reinterpret_cast<float *>(out + (long)x * sb + col);
+#pragma unroll
+                for (int i = 0; i < V; ++i) {
+                    const int zi = z + i;
+                    if (zi >= 1 && zi <= R && zi < a.n2) po[-z - zi] = -res[i];
+                }
+            }
             if (GRAD) {
 #pragma unroll
                 for (int i = 0; i < V; ++i) {

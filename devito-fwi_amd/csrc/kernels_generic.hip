@@ -27,8 +27,19 @@ __global__ __launch_bounds__(256) void step_generic_kernel(StepConsts<T> k, Step
     const T *cur = sp.cur + (long)shot * sp.shot_stride + p;
     const T uc = cur[0];
     T lap = k.c0 * uc;
+    if (k.fs && i2 < 2 * R) {
+        // free surface (operators.py:8-35): in the rows z < space_order a term u[z-j] with a negative
+        // offset becomes sign(z-j) * u[|z-j|]
 #pragma unroll
-    for (int j = 1; j <= R; ++j) lap += k.c[2][j] * (cur[-j] + cur[j]);
+        for (int j = 1; j <= R; ++j) {
+            const int zz = i2 - j;
+            const T lo = zz > 0 ? cur[-j] : (zz < 0 ? -cur[-i2 - zz] : T(0));
+            lap += k.c[2][j] * (lo + cur[j]);
+        }
+    } else {
+#pragma unroll
+        for (int j = 1; j <= R; ++j) lap += k.c[2][j] * (cur[-j] + cur[j]);
+    }
     if (ND >= 2) {
 #pragma unroll
         for (int j = 1; j <= R; ++j) lap += k.c[1][j] * (cur[-j * k.s1] + cur[j * k.s1]);
@@ -104,6 +115,49 @@ template int launch_step_generic<float>(const Plan &, const StepConsts<float> &,
                                         const GradPtrs<float> &, int);
 template int launch_step_generic<double>(const Plan &, const StepConsts<double> &, const StepPtrs<double> &,
                                          const GradPtrs<double> &, int);
+
+// ------------------------------------------------------------------------------------------
+// Born source term (operators.py:263), one thread per point.
+// ------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void born_source_kernel(StepConsts<T> k, const T *u_new, const T *u_cur,
+                                                          const T *u_old, long shot_stride, const T *dm,
+                                                          const T *m, const T *eta, T *U_out, long U_shot_stride,
+                                                          int R, int ghost)
+{
+    const int i2 = blockIdx.x * 64 + threadIdx.x;
+    const int i1 = blockIdx.y * 4 + threadIdx.y;
+    const int shot = blockIdx.z / k.n0;
+    const int i0 = blockIdx.z - shot * k.n0;
+    if (i2 >= k.n2 || i1 >= k.n1) return;
+    const long p = k.off0 + (long)i0 * k.s0 + (long)i1 * k.s1 + i2;
+    const long q = (long)shot * shot_stride + p;
+    const T utt = (u_new[q] - T(2) * u_cur[q] + u_old[q]) * k.inv_dt2;
+    const long o = (long)shot * U_shot_stride + p;
+    const T val = U_out[o] + k.dt2 * (-dm[p] * utt) / (m[p] + eta[p] * k.dt);
+    U_out[o] = val;
+    if (ghost && i2 >= 1 && i2 <= R) U_out[o - 2 * i2] = -val;
+}
+
+template <typename T>
+int launch_born_source(const Plan &p, const StepConsts<T> &k, const T *u_new, const T *u_cur, const T *u_old,
+                       long shot_stride, const T *dm, T *U_out, long U_shot_stride, int nshots, int ghost)
+{
+    if ((long)nshots * k.n0 > 65535) {
+        set_error("born source kernel: nshots * shape[0] exceeds the grid z limit");
+        return MIFWI_EINVAL;
+    }
+    dim3 block(64, 4, 1);
+    dim3 grid((k.n2 + 63) / 64, (k.n1 + 3) / 4, (unsigned)(nshots * k.n0));
+    hipLaunchKernelGGL((born_source_kernel<T>), grid, block, 0, p.stream, k, u_new, u_cur, u_old, shot_stride, dm,
+                       (const T *)p.m, (const T *)p.eta, U_out, U_shot_stride, p.L.R, ghost);
+    MIFWI_HIP(hipGetLastError());
+    return MIFWI_OK;
+}
+template int launch_born_source<float>(const Plan &, const StepConsts<float> &, const float *, const float *,
+                                       const float *, long, const float *, float *, long, int, int);
+template int launch_born_source<double>(const Plan &, const StepConsts<double> &, const double *, const double *,
+                                        const double *, long, const double *, double *, long, int, int);
 
 // ------------------------------------------------------------------------------------------
 // Sparse operations of one time step (seismic/acoustic/operators.py:134,137,173,176,221).

@@ -201,6 +201,15 @@ __global__ __launch_bounds__(256) void step2d_kernel(Step2DArgs a)
             for (int i = 0; i < 4; ++i)
                 if (z + i < a.n2) a.out[ps + i] = res[i];
         }
+        if (a.fs && z <= R) {
+            // free surface: row -zi of the z halo mirrors row zi with the opposite sign, so that the
+            // next step's stencil reads the antisymmetric extension (operators.py:8-35)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int zi = z + i;
+                if (zi >= 1 && zi <= R && zi < a.n2) a.out[ps - z - zi] = -res[i];
+            }
+        }
         if (GRAD) {
             const float u0[4] = {u04.x, u04.y, u04.z, u04.w}, up[4] = {up4.x, up4.y, up4.z, up4.w};
             float g[4] = {gv.x, gv.y, gv.z, gv.w}, il[4] = {iv.x, iv.y, iv.z, iv.w};

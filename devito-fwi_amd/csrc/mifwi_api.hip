@@ -89,6 +89,7 @@ static StepConsts<T> make_consts(const Plan &p)
     k.s1 = p.L.s1;
     k.off0 = p.L.off0;
     k.field = p.L.field;
+    k.fs = (p.cfg.flags & MIFWI_FLAG_FREE_SURFACE) ? 1 : 0;
     return k;
 }
 
@@ -590,6 +591,7 @@ static Step2DArgs base2d(const Plan &p, int nshots)
     a.m = (const float *)p.m;
     a.eta = (const float *)p.eta;
     a.nt = p.cfg.nt;
+    a.fs = (p.cfg.flags & MIFWI_FLAG_FREE_SURFACE) ? 1 : 0;
     return a;
 }
 static void set_inject(Step2DArgs &a, const SparseSet &S, const void *vals)
@@ -676,6 +678,7 @@ static Step3DArgs base3d(const Plan &p, int nshots, bool grad)
     a.m = (const float *)p.m;
     a.eta = (const float *)p.eta;
     a.nt = p.cfg.nt;
+    a.fs = (p.cfg.flags & MIFWI_FLAG_FREE_SURFACE) ? 1 : 0;
     return a;
 }
 static void set_inject3(Step3DArgs &a, const SparseSet &S, const void *vals)
@@ -727,13 +730,13 @@ static LoopCtx<T> make_ctx(const Plan &p, int nshots, bool grad)
 // receivers sample `cur` into d_rec[time].
 template <typename T>
 static int forward_step(Plan &p, const LoopCtx<T> &c, const T *cur, const T *old, T *out, long shot_stride, int time,
-                        bool interp, int &launches)
+                        bool interp, int &launches, bool inject = true)
 {
     int rc;
     if (p.kind == 1) {
         Step2DArgs a = c.a2;
         a.shot_stride = shot_stride;
-        set_inject(a, p.src, p.d_wavelet);
+        if (inject) set_inject(a, p.src, p.d_wavelet);
         if (interp) set_interp(a, p.rec, p.d_rec);
         a.cur = (const float *)cur, a.old = (const float *)old, a.out = (float *)out, a.time = time;
         if ((rc = launch_step2d(p, a, p.stream))) return rc;
@@ -743,7 +746,7 @@ static int forward_step(Plan &p, const LoopCtx<T> &c, const T *cur, const T *old
     if (p.kind == 2) {
         Step3DArgs a = c.a3;
         a.shot_stride = shot_stride;
-        set_inject3(a, p.src, p.d_wavelet);
+        if (inject) set_inject3(a, p.src, p.d_wavelet);
         if (interp) set_interp3(a, p.rec, p.d_rec);
         a.cur = (const float *)cur, a.old = (const float *)old, a.out = (float *)out, a.time = time;
         if ((rc = launch_step3d(p, a, p.stream))) return rc;
@@ -754,9 +757,11 @@ static int forward_step(Plan &p, const LoopCtx<T> &c, const T *cur, const T *old
     GradPtrs<T> gp{};
     if ((rc = launch_step_generic<T>(p, c.k, sp, gp, c.nshots))) return rc;
     SparsePtrs<T> q{};
-    q.inj = &p.src;
-    q.field_inj = out;
-    q.vals_inj = (const T *)p.d_wavelet;
+    if (inject) {
+        q.inj = &p.src;
+        q.field_inj = out;
+        q.vals_inj = (const T *)p.d_wavelet;
+    }
     if (interp) {
         q.itp = &p.rec;
         q.field_int = cur;
@@ -1089,6 +1094,52 @@ static int forward(Plan &p, int nshots, const void *wavelet, int per_shot, void 
     return finish(p);
 }
 
+// Linearised modelling: u in rot_u, U in rot_v, both advanced in one time loop.
+template <typename T>
+static int born(Plan &p, int nshots, const void *wavelet, int per_shot, const void *dm, void *rec_out)
+{
+    int rc;
+    if ((rc = check_run(p, nshots))) return rc;
+    if (!dm) return fail(MIFWI_EINVAL, "dm is null");
+    if ((rc = upload_wavelet<T>(p, nshots, wavelet, per_shot))) return rc;
+    const Layout &L = p.L;
+    const int nt = p.cfg.nt;
+    if (!p.d_dm && (rc = dev_alloc(p, &p.d_dm, (size_t)L.field * sizeof(T), true))) return rc;
+    if ((rc = copy_any(p, p.d_dense, dm, (size_t)L.ngrid * sizeof(T)))) return rc;
+    if ((rc = launch_pack<T>(p, (const T *)p.d_dense, (T *)p.d_dm, L.field, 1))) return rc;
+    T *bu = (T *)p.rot_u, *bU = (T *)p.rot_v;
+    const long stride = 3L * L.field;
+    MIFWI_HIP(hipMemsetAsync(bu, 0, (size_t)nshots * stride * sizeof(T), p.stream));
+    MIFWI_HIP(hipMemsetAsync(bU, 0, (size_t)nshots * stride * sizeof(T), p.stream));
+    MIFWI_HIP(hipMemsetAsync(p.d_rec, 0, (size_t)nshots * nt * p.cfg.nrec * sizeof(T), p.stream));
+    p.rot_u_valid = p.rot_v_valid = false;
+    const LoopCtx<T> ctx = make_ctx<T>(p, nshots, false);
+    const int ghost = (ctx.k.fs && p.kind != 0) ? 1 : 0;
+    auto enqueue = [&](int &launches) -> int {
+        for (int time = 1; time <= nt - 2; ++time) {
+            const long c = (long)(time % 3) * L.field, o = (long)((time + 2) % 3) * L.field,
+                       n = (long)((time + 1) % 3) * L.field;
+            int r;
+            if ((r = forward_step<T>(p, ctx, bu + c, bu + o, bu + n, stride, time, false, launches, true))) return r;
+            if ((r = forward_step<T>(p, ctx, bU + c, bU + o, bU + n, stride, time, true, launches, false))) return r;
+            if ((r = launch_born_source<T>(p, ctx.k, bu + n, bu + c, bu + o, stride, (const T *)p.d_dm, bU + n, stride,
+                                           nshots, ghost)))
+                return r;
+            launches += 1;
+        }
+        return MIFWI_OK;
+    };
+    int launches = 0;
+    float ms = 0;
+    const auto key = std::make_tuple(3, nshots, 0, 0, 0);
+    if ((rc = timed_loop(p, &key, enqueue, launches, ms))) return rc;
+    // two propagations (20 B/pt each) + the source term (3 levels of u, dm, m, eta, U read+write)
+    fill_stats(p, ms, nt - 2, nshots, 72.0, launches, false);
+    p.rot_u_valid = p.rot_v_valid = true;
+    if (rec_out && (rc = copy_any(p, rec_out, p.d_rec, (size_t)nshots * nt * p.cfg.nrec * sizeof(T)))) return rc;
+    return finish(p);
+}
+
 template <typename T>
 static int adjoint(Plan &p, int nshots, const void *rec_in, void *srca_out)
 {
@@ -1307,6 +1358,14 @@ int mifwi_forward(mifwi_plan *plan, int32_t nshots, const void *wavelet, int32_t
     PLAN_OR_FAIL(plan);
     return DISPATCH(forward<float>(p, nshots, wavelet, wavelet_per_shot, rec_out, save),
                     forward<double>(p, nshots, wavelet, wavelet_per_shot, rec_out, save));
+}
+
+int mifwi_born(mifwi_plan *plan, int32_t nshots, const void *wavelet, int32_t wavelet_per_shot, const void *dm,
+               void *rec_out)
+{
+    PLAN_OR_FAIL(plan);
+    return DISPATCH(born<float>(p, nshots, wavelet, wavelet_per_shot, dm, rec_out),
+                    born<double>(p, nshots, wavelet, wavelet_per_shot, dm, rec_out));
 }
 
 int mifwi_adjoint(mifwi_plan *plan, int32_t nshots, const void *rec_in, void *srca_out)

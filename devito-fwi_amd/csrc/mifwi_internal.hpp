@@ -50,6 +50,7 @@ struct StepConsts {
     int n0, n1, n2;
     long s0, s1, off0;
     long field;            // elements per level
+    int fs;                // free surface at the low end of the last dimension
 };
 
 // Sparse point set (sources or receivers) resident on the device.
@@ -117,6 +118,7 @@ struct Plan {
     void *d_res = nullptr;                   // [max_shots][nt][nrec]   adjoint source / residual
     void *d_srca = nullptr;                  // [max_shots][nt][nsrc]
     void *d_grad = nullptr, *d_illum = nullptr; // [max_shots][field] haloed accumulators
+    void *d_dm = nullptr;                    // [field] haloed model perturbation of the Born operator
     void *d_dense = nullptr;                 // dense staging, max(max_shots*ngrid, ...) elements
     size_t dense_elems = 0;
     double *d_partial = nullptr;             // misfit partial sums
@@ -194,6 +196,13 @@ struct SparsePtrs {
 template <typename T>
 int launch_sparse(const Plan &p, const SparsePtrs<T> &sp, int nshots);
 
+// Born source term of one step (seismic/acoustic/operators.py:263): for every grid point
+//   U_out += dt^2 * ( -dm * (u_new - 2 u_cur + u_old) / dt^2 ) / ( m + eta dt )
+// `ghost`: the fields carry the free-surface mirror in their z halo; refresh it for U_out.
+template <typename T>
+int launch_born_source(const Plan &p, const StepConsts<T> &k, const T *u_new, const T *u_cur, const T *u_old,
+                       long shot_stride, const T *dm, T *U_out, long U_shot_stride, int nshots, int ghost);
+
 template <typename T>
 int launch_prep_model(const Plan &p, const T *vp_dense, const T *damp_dense, T *m, T *eta);
 
@@ -241,6 +250,7 @@ struct Step2DArgs {
     int itp_npoint, itp_per_shot;
     float *vals_out;
     int time, nt;
+    int fs;   // free surface: keep the antisymmetric mirror of rows z = 1..R in the z halo of `out`
 };
 int launch_step2d(const Plan &p, const Step2DArgs &a, hipStream_t stream);
 
@@ -273,6 +283,7 @@ struct Step3DArgs {
     int itp_npoint, itp_per_shot;
     float *vals_out;
     int time, nt;
+    int fs;   // free surface: keep the antisymmetric mirror of rows z = 1..R in the z halo of `out`
 };
 int launch_step3d(const Plan &p, const Step3DArgs &a, hipStream_t stream);
 int launch_eta_zero(const Plan &p, unsigned char *flags);

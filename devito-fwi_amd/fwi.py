@@ -173,8 +173,10 @@ def _batch_entry(geometry, shots):
     model = geometry.model
     model._initialize_bcs(bcs="damp")
     nt = geometry.nt
+    from mifwi import FLAG_FREE_SURFACE
     entry = engine.get_plan(model.grid.shape, model.spacing, model.grid.origin, model.space_order, nt,
-                            model.critical_dt, 1, geometry.nrec, max_shots=len(shots), dtype=model.dtype)
+                            model.critical_dt, 1, geometry.nrec, max_shots=len(shots), dtype=model.dtype,
+                            flags=FLAG_FREE_SURFACE if getattr(model, 'fs', False) else 0)
     vp = model.vp.data
     if np.ndim(vp) == 0:
         vp = np.full(model.grid.shape, vp, dtype=model.dtype)
@@ -371,10 +373,10 @@ def fwi_obj_single(geometry, obs, misfit_func, direct_wave=None, resample_dt=Non
     if calc_grad:
         grad = Function(name="grad", grid=geometry.model.grid)
         solver.gradient(rec=residual, u=wfd, vp=geometry.model.vp, grad=grad)
-        nbl = geometry.model.nbl
-        crop_grad = np.array(grad.data[:])[nbl:-nbl, nbl:-nbl]
+        crop = geometry.model.physical_slices
+        crop_grad = np.array(grad.data[:])[crop]
         crop_grad = fix_source_illumination(geometry, crop_grad)
-        illum = (wfd.data * wfd.data).sum(axis=0)[nbl:-nbl, nbl:-nbl]
+        illum = (wfd.data * wfd.data).sum(axis=0)[crop]
         illum = fix_source_illumination(geometry, illum)
     return fval, crop_grad, residual.data, illum
 
@@ -416,7 +418,7 @@ def fwi_obj_multi(geometry, obs, misfit_func, direct_wave=None, mask=None, preco
                 illum += il_
     elif mine:
         fvals, res_b, g_b, il_b = _compute_batch(geometry, mine, obs, direct_wave, misfit_func, calc_grad)
-        crop = tuple(slice(nbl, -nbl) if nbl else slice(None) for _ in range(model.dim))
+        crop = model.physical_slices
         for k, i in enumerate(mine):
             fval += float(fvals[k])
             residuals._set(i, res_b, k)

@@ -4,4 +4,5 @@ ctypes binding of libmifwi.so, the MI355X-native acoustic propagator library
 shared library loads, but creating a plan without a GPU raises.
 """
 from ._lib import (Plan, MifwiError, load_library, library_path, EXPORTED_SYMBOLS,  # noqa: F401
-                   F32, F64, FLAG_ASYNC, FLAG_NO_GRAPH, FLAG_GENERIC, FLAG_CHECKPOINT)
+                   F32, F64, FLAG_ASYNC, FLAG_NO_GRAPH, FLAG_GENERIC, FLAG_CHECKPOINT,
+                   FLAG_FREE_SURFACE)

@@ -6,14 +6,14 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 
 F32, F64 = 0, 1
-FLAG_ASYNC, FLAG_NO_GRAPH, FLAG_GENERIC, FLAG_CHECKPOINT = 1, 2, 4, 8
+FLAG_ASYNC, FLAG_NO_GRAPH, FLAG_GENERIC, FLAG_CHECKPOINT, FLAG_FREE_SURFACE = 1, 2, 4, 8, 16
 
 # every symbol include/mifwi.h declares
 EXPORTED_SYMBOLS = (
     "mifwi_version", "mifwi_last_error", "mifwi_plan_create", "mifwi_plan_destroy", "mifwi_set_stream",
     "mifwi_synchronize", "mifwi_set_model", "mifwi_set_geometry", "mifwi_forward", "mifwi_adjoint",
     "mifwi_gradient", "mifwi_l2_misfit_gradient", "mifwi_read_wavefield", "mifwi_write_wavefield",
-    "mifwi_get_stats",
+    "mifwi_get_stats", "mifwi_born",
 )
 
 
@@ -72,6 +72,7 @@ def load_library():
     lib.mifwi_set_geometry.argtypes = [vp, i32, vp, vp, i32]
     lib.mifwi_forward.argtypes = [vp, i32, vp, i32, vp, i32]
     lib.mifwi_adjoint.argtypes = [vp, i32, vp, vp]
+    lib.mifwi_born.argtypes = [vp, i32, vp, i32, vp, vp]
     lib.mifwi_gradient.argtypes = [vp, i32, vp, vp, i32, vp]
     lib.mifwi_l2_misfit_gradient.argtypes = [vp, i32, vp, i32, vp, vp, vp, vp, vp, vp]
     lib.mifwi_read_wavefield.argtypes = [vp, i32, i32, i32, i32, vp]
@@ -195,6 +196,17 @@ class Plan(object):
         if want_rec:
             pr, rec = self._out(rec_out, (nshots, self.nt, self.nrec))
         self._check(self._lib.mifwi_forward(self._h, nshots, pw, int(bool(wavelet_per_shot)), pr, int(bool(save))))
+        return rec
+
+    def born(self, wavelet, dm, nshots=None, rec_out=None, wavelet_per_shot=False):
+        """Linearised data (nshots, nt, nrec) for the model perturbation dm (padded grid)."""
+        nshots = nshots or self.nshots
+        pw, kw = self._in(wavelet)
+        pd, kd = self._in(dm)
+        n = kd.numel() if _is_torch(kd) else kd.size
+        assert n == self.ngrid, "dm must cover the padded grid"
+        pr, rec = self._out(rec_out, (nshots, self.nt, self.nrec))
+        self._check(self._lib.mifwi_born(self._h, nshots, pw, int(bool(wavelet_per_shot)), pd, pr))
         return rec
 
     def adjoint(self, rec_in, nshots=None, srca_out=None):

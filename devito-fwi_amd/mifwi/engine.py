@@ -47,16 +47,16 @@ _CACHE = collections.OrderedDict()
 _MAX_PLANS = 4
 
 
-def _key(shape, spacing, origin, space_order, nt, dt, nsrc, nrec, max_shots, dtype, device):
+def _key(shape, spacing, origin, space_order, nt, dt, nsrc, nrec, max_shots, dtype, device, flags=0):
     return (tuple(int(s) for s in shape), tuple(float(s) for s in spacing), tuple(float(o) for o in origin),
             int(space_order), int(nt), float(dt), int(nsrc), int(nrec), int(max_shots), np.dtype(dtype).str,
-            int(device))
+            int(device), int(flags))
 
 
 def get_plan(shape, spacing, origin, space_order, nt, dt, nsrc, nrec, max_shots=1, dtype=np.float32,
              device=-1, flags=0):
     """Return a cached PlanEntry for this discretisation, creating (and evicting) as needed."""
-    key = _key(shape, spacing, origin, space_order, nt, dt, nsrc, nrec, max_shots, dtype, device)
+    key = _key(shape, spacing, origin, space_order, nt, dt, nsrc, nrec, max_shots, dtype, device, flags)
     entry = _CACHE.get(key)
     if entry is not None:
         _CACHE.move_to_end(key)

@@ -1,9 +1,9 @@
 """
 `AcousticWaveSolver` with the call signatures of the reference's
 seismic/acoustic/wavesolver.py:10-246, executing on an MI355X through libmifwi instead of
-through Devito-generated C.  forward / adjoint / jacobian_adjoint (alias gradient) are
-implemented; jacobian (Born), the OT4 kernel and pyrevolve checkpointing are not part of this
-package yet and raise.
+through Devito-generated C.  forward / adjoint / jacobian (alias born) / jacobian_adjoint (alias
+gradient) are implemented, with or without a free surface; the OT4 kernel and the pyrevolve
+`checkpointing=True` keyword are not part of this package and raise.
 """
 import numpy as np
 
@@ -35,7 +35,7 @@ def _as_vp_array(vp, model):
     if data.shape == model.grid.shape:
         return data
     if data.shape == model.shape:
-        return np.pad(data, model.nbl, mode='edge') if model.nbl else data
+        return np.pad(data, model.padsizes, mode='edge') if model.nbl else data
     raise ValueError("vp of shape %s does not match the model" % (data.shape,))
 
 
@@ -65,8 +65,10 @@ class AcousticWaveSolver(object):
     def _entry(self, dt, nsrc, nrec, nt):
         from mifwi import engine
         m = self.model
+        from mifwi import FLAG_FREE_SURFACE
         return engine.get_plan(m.grid.shape, m.spacing, m.grid.origin, self.space_order, nt, dt, nsrc, nrec,
-                               max_shots=1, dtype=m.dtype, device=self._device)
+                               max_shots=1, dtype=m.dtype, device=self._device,
+                               flags=FLAG_FREE_SURFACE if getattr(m, 'fs', False) else 0)
 
     def _damp_array(self):
         d = self.model.damp
@@ -142,7 +144,38 @@ class AcousticWaveSolver(object):
         return grad, PerformanceSummary(entry.plan.stats())
 
     def jacobian(self, dmin, src=None, rec=None, u=None, U=None, vp=None, **kwargs):
-        raise NotImplementedError("Born modelling (wavesolver.py:207-242 of the reference) is not implemented yet")
+        """Linearised Born modelling for the perturbation `dmin` of 1/vp^2 (array over the padded or
+        the physical grid, or a Function); returns (rec, u, U, summary) (wavesolver.py:207-242)."""
+        src = src or self.geometry.src
+        rec = rec or self.geometry.rec
+        dt = kwargs.pop('dt', self.dt)
+        nt = src.data.shape[0]
+        dm = np.asarray(dmin.data if hasattr(dmin, 'data') else dmin, dtype=self.model.dtype)
+        if dm.shape == self.model.shape and dm.shape != self.model.grid.shape:
+            dm = np.pad(dm, self.model.padsizes, mode='constant')
+        if dm.shape != self.model.grid.shape:
+            raise ValueError("dmin of shape %s does not match the model" % (dm.shape,))
+        entry = self._entry(dt, src.data.shape[1], rec.data.shape[1], nt)
+        self._load(entry, vp, src.coordinates.data, rec.coordinates.data)
+        out_u, out_U = u, U
+        if u is None:
+            out_u = DeviceTimeFunction('u', self.model.grid, None, entry, None, 1, time_order=2,
+                                       space_order=self.space_order)
+        if U is None:
+            out_U = DeviceTimeFunction('U', self.model.grid, None, entry, None, 2, time_order=2,
+                                       space_order=self.space_order)
+        tok_u = entry.claim(1, out_u if u is None else None)
+        tok_U = entry.claim(2, out_U if U is None else None)
+        rec.data[:] = entry.plan.born(src.data, np.ascontiguousarray(dm), nshots=1)[0]
+        if u is None:
+            out_u._token = tok_u
+        else:
+            u.data[...] = entry.plan.read_wavefield(1, shot=0)
+        if U is None:
+            out_U._token = tok_U
+        else:
+            U.data[...] = entry.plan.read_wavefield(2, shot=0)
+        return rec, out_u, out_U, PerformanceSummary(entry.plan.stats())
 
     # Backward compatibility
     born = jacobian

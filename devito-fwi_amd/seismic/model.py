@@ -4,8 +4,7 @@ Host-side physical model: padded grid, edge-padded velocity, sponge profile, CFL
 Mirrors the interface of the reference's seismic/model.py (`SeismicModel`, alias `Model`) for the
 isotropic acoustic case with numpy arrays in place of Devito functions; every attribute the FWI
 drivers and `AcousticWaveSolver` touch is present with the same meaning (reference file:line
-given per member).  Elastic / visco / TTI parameters and the free surface are outside this
-package's scope and raise.
+given per member).  Elastic / visco / TTI parameters are outside this package's scope and raise.
 """
 import numpy as np
 
@@ -59,8 +58,6 @@ class GenericModel(object):
 
     def __init__(self, origin, spacing, shape, space_order, nbl=20, dtype=np.float32, subdomains=(),
                  bcs="damp", grid=None, fs=False):
-        if fs:
-            raise NotImplementedError("free-surface models are not supported by the MI355X propagators yet")
         self.shape = tuple(int(s) for s in shape)
         self.space_order = space_order
         self.nbl = int(nbl)
@@ -69,6 +66,10 @@ class GenericModel(object):
         self.fs = fs
         origin_pml = [dtype(o - s * self.nbl) for o, s in zip(origin, spacing)]   # model.py:100
         shape_pml = np.array(self.shape) + 2 * self.nbl
+        if fs:
+            # free surface at the low end of the last dimension: no layer there (model.py:106-110)
+            origin_pml[-1] = dtype(origin[-1])
+            shape_pml[-1] -= self.nbl
         if grid is None:
             extent = tuple(np.array(spacing, dtype=np.float64) * (shape_pml - 1))
             self.grid = Grid(extent=extent, shape=tuple(shape_pml), origin=origin_pml, dtype=dtype)
@@ -97,7 +98,16 @@ class GenericModel(object):
 
     @property
     def padsizes(self):
-        return [(self.nbl, self.nbl) for _ in range(self.dim)]
+        """(low, high) layer widths per dimension (model.py:151-158)."""
+        pads = [(self.nbl, self.nbl) for _ in range(self.dim)]
+        if self.fs:
+            pads[-1] = (0, self.nbl)
+        return pads
+
+    @property
+    def physical_slices(self):
+        """Index of the physical domain inside a padded-grid array."""
+        return tuple(slice(lo, n - hi) for (lo, hi), n in zip(self.padsizes, self.grid.shape))
 
     @property
     def physical_parameters(self):
@@ -161,7 +171,7 @@ class SeismicModel(GenericModel):
         if field.shape != self.shape:
             raise ValueError("Incorrect input size %s for model %s without or %s with padding"
                              % (field.shape, self.shape, self.grid.shape))
-        return np.pad(field, self.nbl, mode='edge') if self.nbl else field
+        return np.pad(field, self.padsizes, mode='edge') if self.nbl else field
 
     def _gen_phys_param(self, field, name, space_order, is_param=True, default_value=0):
         if field is None:

@@ -57,8 +57,12 @@ enum {
     MIFWI_FLAG_ASYNC = 1,        /* do not synchronise at the end of each call            */
     MIFWI_FLAG_NO_GRAPH = 2,     /* launch kernels one by one instead of replaying a graph */
     MIFWI_FLAG_GENERIC = 4,      /* force the untiled reference kernels                    */
-    MIFWI_FLAG_CHECKPOINT = 8    /* keep the forward wavefield as checkpoints + recomputation
+    MIFWI_FLAG_CHECKPOINT = 8,   /* keep the forward wavefield as checkpoints + recomputation
                                     even when every level would fit (automatic otherwise)  */
+    MIFWI_FLAG_FREE_SURFACE = 16 /* free surface at the low end of the LAST dimension: the model was
+                                    built with fs=True (seismic/model.py:100-110,157: no absorbing
+                                    layer there) and the stencil mirrors the field antisymmetrically
+                                    about index 0 (seismic/acoustic/operators.py:8-35,92-94)   */
 };
 
 typedef struct mifwi_plan mifwi_plan; /* opaque */
@@ -131,6 +135,15 @@ int mifwi_set_geometry(mifwi_plan *plan, int32_t nshots, const void *src_coords,
  * mifwi_gradient / mifwi_read_wavefield. */
 int mifwi_forward(mifwi_plan *plan, int32_t nshots, const void *wavelet, int32_t wavelet_per_shot,
                   void *rec_out, int32_t save);
+
+/* Replaces: AcousticWaveSolver.jacobian (= born) -> op_born().apply(dm, src, rec, u, U, vp, dt)
+ * (seismic/acoustic/wavesolver.py:207-242; seismic/acoustic/operators.py:228-273): linearised
+ * modelling.  The background field u is driven by the wavelet, the scattered field U by
+ * -dm * u.dt2; rec_out (nshots, nt, nrec) receives the samples of U.  dm: (grid), one model
+ * perturbation (of 1/vp^2) shared by all shots.  Afterwards mifwi_read_wavefield(which = 1) gives
+ * the last three levels of u and which = 2 those of U. */
+int mifwi_born(mifwi_plan *plan, int32_t nshots, const void *wavelet, int32_t wavelet_per_shot,
+               const void *dm, void *rec_out);
 
 /* Replaces: AcousticWaveSolver.adjoint -> op_adj().apply(srca, rec, v, vp, dt)
  * (seismic/acoustic/wavesolver.py:116-151; seismic/acoustic/operators.py:143-180).

@@ -93,19 +93,25 @@ def critical_dt(vp_max, spacing, space_order, dtype=np.float32, dt=None):
     return cdt
 
 
-def sponge(shape_pad, nbl, spacing, dtype=np.float32):
-    """seismic/model.py:13-51 (abc_type='damp', fs=False)."""
+def sponge(shape_pad, nbl, spacing, dtype=np.float32, fs=False):
+    """seismic/model.py:13-51 (abc_type='damp'); with fs no layer at the low end of the last dim."""
     dtype = np.dtype(dtype)
     out = np.zeros(tuple(shape_pad), dtype=dtype)
     fn = getattr(lib(), "oracle_sponge_" + _sfx(dtype))
-    rc = fn(len(shape_pad), _ia(shape_pad), int(nbl), _da(spacing), _p(out))
+    rc = fn(len(shape_pad), _ia(shape_pad), int(nbl), _da(spacing), _p(out), int(bool(fs)))
     assert rc == 0
     return out
 
 
-def pad_vp(vp, nbl):
-    """seismic/model.py:174,387: initialize_function replicates edge values into the layer."""
-    return np.pad(vp, nbl, mode="edge") if nbl > 0 else np.array(vp)
+def pad_vp(vp, nbl, fs=False):
+    """seismic/model.py:157,174,387: initialize_function replicates edge values into the layer
+    (padsizes (nbl, nbl) per dimension, (0, nbl) for the last one under a free surface)."""
+    if nbl <= 0:
+        return np.array(vp)
+    widths = [(nbl, nbl)] * vp.ndim
+    if fs:
+        widths[-1] = (0, nbl)
+    return np.pad(vp, widths, mode="edge")
 
 
 def time_axis(t0, tn, dt):
@@ -135,7 +141,7 @@ class Problem(object):
     """
 
     def __init__(self, vp, spacing, nbl, space_order, origin=None, dtype=np.float32, dt=None,
-                 model_space_order=None):
+                 model_space_order=None, fs=False):
         self.dtype = np.dtype(dtype)
         vp = np.asarray(vp, dtype=self.dtype)
         self.ndim = vp.ndim
@@ -147,15 +153,20 @@ class Problem(object):
         self.model_space_order = int(model_space_order or space_order)
         self.user_dt = dt
         # model.py:100: origin_pml = dtype(o - s*nbl)
-        self.origin_pad = tuple(float(self.dtype.type(o - s * self.nbl)) for o, s in zip(self.origin, self.spacing))
-        self.shape_pad = tuple(s + 2 * self.nbl for s in self.shape)
-        self.damp = sponge(self.shape_pad, self.nbl, self.spacing, self.dtype)
+        self.fs = bool(fs)
+        origin_pad = [float(self.dtype.type(o - s * self.nbl)) for o, s in zip(self.origin, self.spacing)]
+        shape_pad = [s + 2 * self.nbl for s in self.shape]
+        if self.fs:                                   # model.py:106-110
+            origin_pad[-1] = float(self.dtype.type(self.origin[-1]))
+            shape_pad[-1] -= self.nbl
+        self.origin_pad, self.shape_pad = tuple(origin_pad), tuple(shape_pad)
+        self.damp = sponge(self.shape_pad, self.nbl, self.spacing, self.dtype, self.fs)
         self.set_vp(vp)
 
     def set_vp(self, vp):
         vp = np.asarray(vp, dtype=self.dtype)
         if vp.shape == self.shape:
-            self.vp = np.ascontiguousarray(pad_vp(vp, self.nbl))
+            self.vp = np.ascontiguousarray(pad_vp(vp, self.nbl, self.fs))
         elif vp.shape == self.shape_pad:
             self.vp = np.ascontiguousarray(vp)
         else:
@@ -181,7 +192,7 @@ class Problem(object):
         fn = getattr(lib(), "oracle_forward_" + _sfx(self.dtype))
         rc = fn(self.ndim, _ia(self.shape_pad), _da(self.spacing), _da(self.origin_pad), self.space_order,
                 nt, ctypes.c_double(dt), _p(vp), _p(self.damp), sc.shape[0], _p(sc), _p(w),
-                rc_.shape[0], _p(rc_), _p(rec), _p(u), _p(ul))
+                rc_.shape[0], _p(rc_), _p(rec), _p(u), _p(ul), int(self.fs))
         assert rc == 0, rc
         out = (rec, u)
         return out + (ul,) if return_last else out
@@ -197,7 +208,7 @@ class Problem(object):
         fn = getattr(lib(), "oracle_adjoint_" + _sfx(self.dtype))
         rc = fn(self.ndim, _ia(self.shape_pad), _da(self.spacing), _da(self.origin_pad), self.space_order,
                 nt, ctypes.c_double(dt), _p(vp), _p(self.damp), sc.shape[0], _p(sc), _p(srca),
-                rc_.shape[0], _p(rc_), _p(rec), None)
+                rc_.shape[0], _p(rc_), _p(rec), None, int(self.fs))
         assert rc == 0, rc
         return srca
 
@@ -216,9 +227,26 @@ class Problem(object):
         fn = getattr(lib(), "oracle_gradient_" + _sfx(self.dtype))
         rc = fn(self.ndim, _ia(self.shape_pad), _da(self.spacing), _da(self.origin_pad), self.space_order,
                 nt, ctypes.c_double(dt), _p(vp), _p(self.damp), rc_.shape[0], _p(rc_), _p(residual),
-                _p(u), _p(grad))
+                _p(u), _p(grad), int(self.fs))
         assert rc == 0, rc
         return grad
+
+    def born(self, src_coords, wavelet, rec_coords, dm, dt=None, vp=None):
+        """operators.py:228-273.  dm over the padded grid.  Returns the linearised data (nt,nrec)."""
+        dt = float(self.critical_dt if dt is None else dt)
+        vp = self.vp if vp is None else np.ascontiguousarray(vp, dtype=self.dtype)
+        sc, rc_ = self._coords(src_coords), self._coords(rec_coords)
+        w = np.ascontiguousarray(np.asarray(wavelet, dtype=self.dtype).reshape(-1, sc.shape[0]))
+        dm = np.ascontiguousarray(dm, dtype=self.dtype)
+        assert dm.shape == self.shape_pad
+        nt = w.shape[0]
+        rec = np.zeros((nt, rc_.shape[0]), dtype=self.dtype)
+        fn = getattr(lib(), "oracle_born_" + _sfx(self.dtype))
+        rc = fn(self.ndim, _ia(self.shape_pad), _da(self.spacing), _da(self.origin_pad), self.space_order,
+                nt, ctypes.c_double(dt), _p(vp), _p(self.damp), _p(dm), sc.shape[0], _p(sc), _p(w),
+                rc_.shape[0], _p(rc_), _p(rec), int(self.fs))
+        assert rc == 0, rc
+        return rec
 
 
 # ----------------------------------------------------------------------------------------------

@@ -26,11 +26,12 @@ class Case(object):
     """A small acquisition: oracle problem + geometry + wavelet, all seeded."""
 
     def __init__(self, shape, spacing, nbl, space_order, nt=None, tn=None, nshots=2, nrec=11, nsrc=1,
-                 dtype=np.float32, seed=0, f0=0.015, vp=None):
+                 dtype=np.float32, seed=0, f0=0.015, vp=None, fs=False):
         self.dtype = np.dtype(dtype)
         self.ndim = len(shape)
         vp = smooth_random_vp(shape, seed=seed) if vp is None else vp
-        self.prob = orc.Problem(vp.astype(self.dtype), spacing, nbl, space_order, dtype=self.dtype)
+        self.fs = bool(fs)
+        self.prob = orc.Problem(vp.astype(self.dtype), spacing, nbl, space_order, dtype=self.dtype, fs=fs)
         self.dt = float(self.prob.critical_dt)
         if nt is None:
             nt, tv = orc.time_axis(0.0, tn, self.dt)
@@ -55,7 +56,8 @@ class Case(object):
     def plan(self, mifwi, max_shots=None, flags=0):
         p = self.prob
         plan = mifwi.Plan(p.shape_pad, p.spacing, p.origin_pad, p.space_order, self.nt, self.dt, self.nsrc,
-                          self.nrec, max_shots=max_shots or self.nshots, dtype=self.dtype, flags=flags)
+                          self.nrec, max_shots=max_shots or self.nshots, dtype=self.dtype,
+                          flags=flags | (16 if self.fs else 0))
         plan.set_model(p.vp, p.damp)
         plan.set_geometry(self.src, self.rec)
         return plan
@@ -69,3 +71,6 @@ class Case(object):
 
     def oracle_gradient(self, residual, u):
         return self.prob.gradient(self.rec, residual, u, dt=self.dt)
+
+    def oracle_born(self, shot, dm):
+        return self.prob.born(self.src[shot], self.wavelet, self.rec, dm, dt=self.dt)

@@ -1,0 +1,159 @@
+"""
+GPU parity of the free-surface variant (MIFWI_FLAG_FREE_SURFACE; reference
+seismic/acoustic/operators.py:8-35) and of linearised Born modelling (mifwi_born; reference
+operators.py:228-273, wavesolver.py:207-242) against the CPU oracle, plus the reference's
+free-surface known-answer test (seismic/acoustic/acoustic_example.py:75-79: norm 369.955,
+rtol 1e-3, float32) through the drop-in solver API.
+
+Tolerances as in test_gpu_parity_abi.py: rel-L2 <= 1e-5 on records/wavefields, <= 1e-4 on
+gradients (float32); 1e-11 / 1e-10 in float64.
+"""
+import numpy as np
+import pytest
+
+from helpers import Case, rel_l2, smooth_random_vp
+from test_gpu_parity_abi import _check_case, TOL
+from kat_setups import layers3d_kat
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def mifwi():
+    import mifwi as m
+    return m
+
+
+def _shallow(case):
+    """Move sources and receivers into the first cells below the surface, where the mirror acts."""
+    h = case.prob.spacing[-1]
+    case.src[..., -1] = (1.0 + np.arange(case.src.shape[0])[:, None] * 0.37) * h
+    case.rec[:, -1] = 2.3 * h
+    return case
+
+
+@pytest.mark.parametrize("flags", [0, 4])
+@pytest.mark.parametrize("so", [4, 8, 16])
+def test_2d_free_surface(mifwi, so, flags):
+    case = _shallow(Case((47, 40), (10.0, 10.0), nbl=9, space_order=so, nt=150, nshots=2, nrec=13, fs=True))
+    assert case.prob.shape_pad == (65, 49)
+    _check_case(mifwi, case, flags)
+
+
+def test_2d_free_surface_differs_from_absorbing_top(mifwi):
+    fs = _shallow(Case((47, 40), (10.0, 10.0), nbl=9, space_order=8, nt=150, nshots=1, nrec=13, fs=True))
+    ab = Case((47, 40), (10.0, 10.0), nbl=9, space_order=8, nt=150, nshots=1, nrec=13, fs=False)
+    ab.src[:], ab.rec[:] = fs.src, fs.rec
+    r_fs = fs.plan(mifwi).forward(fs.wavelet)
+    r_ab = ab.plan(mifwi).forward(ab.wavelet)
+    assert rel_l2(r_fs, r_ab) > 0.3          # the surface reflection is a first-order effect
+
+
+@pytest.mark.parametrize("flags", [0, 4])
+def test_3d_free_surface(mifwi, flags):
+    case = _shallow(Case((22, 27, 70), (10.0, 10.0, 10.0), nbl=6, space_order=8, nt=60, nshots=2, nrec=9,
+                         fs=True, seed=4))
+    _check_case(mifwi, case, flags)
+
+
+def test_3d_free_surface_so16(mifwi):
+    case = _shallow(Case((20, 21, 66), (10.0, 10.0, 10.0), nbl=5, space_order=16, nt=40, nshots=1, nrec=9,
+                         fs=True, seed=5))
+    _check_case(mifwi, case, 0)
+
+
+def test_f64_free_surface(mifwi):
+    case = _shallow(Case((30, 33), (10.0, 10.0), nbl=7, space_order=6, nt=100, nshots=1, nrec=9, fs=True,
+                         dtype=np.float64))
+    _check_case(mifwi, case, 0)
+
+
+def _dm(case, seed=9):
+    rng = np.random.default_rng(seed)
+    dm = smooth_random_vp(case.prob.shape_pad, vmin=-0.02, vmax=0.02, seed=seed, passes=2)
+    return np.ascontiguousarray(dm, dtype=case.dtype)
+
+
+@pytest.mark.parametrize("flags", [0, 4])
+@pytest.mark.parametrize("fs", [False, True])
+def test_2d_born(mifwi, fs, flags):
+    case = Case((45, 38), (10.0, 12.5), nbl=9, space_order=8, nt=160, nshots=2, nrec=13, fs=fs)
+    if fs:
+        _shallow(case)
+    dm = _dm(case)
+    plan = case.plan(mifwi, flags=flags)
+    lin = plan.born(case.wavelet, dm)
+    for s in range(case.nshots):
+        ref = case.oracle_born(s, dm)
+        assert np.abs(ref).max() > 0
+        assert rel_l2(lin[s], ref) <= 1e-4, s
+    # the background field left behind equals that of a plain forward run
+    u_born = plan.read_wavefield(1, shot=1)
+    plan.forward(case.wavelet)
+    assert rel_l2(u_born, plan.read_wavefield(1, shot=1)) <= 1e-6
+    plan.close()
+
+
+@pytest.mark.parametrize("flags", [0, 4])
+def test_3d_born(mifwi, flags):
+    case = Case((20, 23, 66), (10.0, 10.0, 10.0), nbl=5, space_order=8, nt=50, nshots=1, nrec=9, seed=6)
+    dm = _dm(case)
+    plan = case.plan(mifwi, flags=flags)
+    lin = plan.born(case.wavelet, dm)
+    assert rel_l2(lin[0], case.oracle_born(0, dm)) <= 1e-4
+    plan.close()
+
+
+def test_born_f64_and_adjoint_pair(mifwi):
+    """<J dm, r> = <dm, J^T r> on the GPU (float64, generic kernels): the pairing the reference's
+    solver exposes as jacobian / jacobian_adjoint."""
+    case = Case((33, 31), (10.0, 10.0), nbl=8, space_order=4, nt=120, nshots=1, nrec=11, dtype=np.float64)
+    dm = _dm(case)
+    dm[:case.prob.nbl] = dm[-case.prob.nbl:] = 0
+    dm[:, :case.prob.nbl] = dm[:, -case.prob.nbl:] = 0
+    plan = case.plan(mifwi)
+    lin = plan.born(case.wavelet, dm)
+    assert rel_l2(lin[0], case.oracle_born(0, dm)) <= 1e-11
+    rng = np.random.default_rng(2)
+    r = rng.standard_normal(lin.shape) * (np.arange(case.nt)[None, :, None] > 2)
+    plan.forward(case.wavelet, save=True)
+    g = plan.gradient(r)
+    lhs, rhs = float(np.sum(lin * r)), float(np.sum(g[0] * dm))
+    assert abs(lhs - rhs) <= 1e-9 * max(abs(lhs), abs(rhs))
+    plan.close()
+
+
+def test_kat_free_surface_through_solver_api():
+    """acoustic_example.py:75-79 with fs=True: ||rec|| = 369.955 (rtol 1e-3), float32."""
+    from seismic import demo_model, setup_geometry
+    from seismic.acoustic import AcousticWaveSolver
+    c = layers3d_kat()
+    model = demo_model('layers-isotropic', space_order=4, shape=c["shape"], nbl=c["nbl"], dtype=np.float32,
+                       spacing=c["spacing"], fs=True)
+    assert model.grid.shape == (130, 130, 90)
+    geometry = setup_geometry(model, c["tn"])
+    solver = AcousticWaveSolver(model, geometry, kernel='OT2', space_order=4)
+    rec, u, summary = solver.forward(save=False)
+    nrm = np.linalg.norm(rec.data.ravel().astype(np.float64))
+    print("free-surface KAT on GPU:", nrm)
+    assert np.isclose(nrm, 369.955, rtol=1e-3, atol=0)
+
+
+def test_solver_jacobian_matches_oracle():
+    from seismic import demo_model, setup_geometry
+    from seismic.acoustic import AcousticWaveSolver
+    from oracle import oracle as orc
+    model = demo_model('layers-isotropic', space_order=8, shape=(60, 50), nbl=12, dtype=np.float32,
+                       spacing=(10.0, 10.0), nlayers=3)
+    geometry = setup_geometry(model, 400.0)
+    solver = AcousticWaveSolver(model, geometry, space_order=8)
+    dm_phys = smooth_random_vp(model.shape, vmin=-0.03, vmax=0.03, seed=21, passes=2).astype(np.float32)
+    rec, u, U, summary = solver.born(dm_phys)
+    nbl = model.nbl
+    prob = orc.Problem(np.asarray(model.vp.data)[nbl:-nbl, nbl:-nbl], model.spacing, nbl, 8,
+                       origin=model.origin, dt=float(model.critical_dt))
+    ref = prob.born(geometry.src_positions, geometry.src.data, geometry.rec_positions,
+                    np.pad(dm_phys, nbl), dt=float(model.critical_dt))
+    assert rel_l2(rec.data, ref) <= 1e-4
+    assert U.data.shape == (3,) + model.grid.shape and np.abs(U.data).max() > 0
+    assert summary.gpointss > 0

@@ -102,3 +102,56 @@ def test_kat_layers3d_forward_f64():
     nrm = np.linalg.norm(rec.ravel())
     print("layers3d KAT: dt", dt, "nt", nt, "norm", nrm)
     assert np.isclose(nrm, c["kat"]["norm_rec"], rtol=c["kat"]["rtol"], atol=0)
+
+
+@pytest.mark.slow
+def test_kat_layers3d_forward_f32_free_surface():
+    """seismic/acoustic/acoustic_example.py:75-79, (fs=True, 369.955, float32)."""
+    c = layers3d_kat()
+    prob = orc.Problem(c["vp"].astype(np.float32), c["spacing"], c["nbl"], c["space_order"], dtype=np.float32,
+                       fs=True)
+    assert prob.shape_pad == (130, 130, 90) and prob.origin_pad[-1] == 0.0
+    dt = prob.critical_dt
+    nt, tv = orc.time_axis(c["t0"], c["tn"], float(dt))
+    wavelet = orc.ricker(c["f0"], tv).reshape(nt, 1)
+    rec, _ = prob.forward(c["src_positions"], wavelet, c["rec_positions"], dt=dt)
+    nrm = np.linalg.norm(rec.ravel().astype(np.float64))
+    print("layers3d free-surface KAT: dt", dt, "nt", nt, "norm", nrm)
+    assert np.isclose(nrm, 369.955, rtol=1e-3, atol=0)
+
+
+def test_born_is_the_derivative_of_forward_and_adjoint_of_gradient():
+    """Linearisation check of the Born restatement (operators.py:228-273): F(m + eps dm) - F(m)
+    -> eps J dm; and <J dm, r> against <dm, J^T r> with J^T = the gradient operator
+    (operators.py:183-225), which the reference's solver pairs as jacobian / jacobian_adjoint
+    (wavesolver.py:153-246)."""
+    rng = np.random.default_rng(5)
+    shape, spacing, nbl, so = (41, 37), (10.0, 10.0), 12, 4
+    vp = (1.8 + 0.4 * rng.random(shape)).astype(np.float64)
+    from scipy.ndimage import gaussian_filter
+    vp = gaussian_filter(vp, 3)
+    prob = orc.Problem(vp, spacing, nbl, so, dtype=np.float64)
+    dt = float(prob.critical_dt)
+    nt, tv = orc.time_axis(0.0, 400.0, dt)
+    w = orc.ricker(0.02, tv).reshape(nt, 1)
+    src = np.array([[203.0, 31.0]])
+    rec = np.stack([np.linspace(15.0, 385.0, 19), np.full(19, 27.0)], axis=1)
+    dm_phys = gaussian_filter(rng.standard_normal(shape), 2) * 0.02
+    dm = np.zeros(prob.shape_pad)
+    dm[nbl:-nbl, nbl:-nbl] = dm_phys
+    d0, u = prob.forward(src, w, rec, dt=dt, save=True)
+    lin = prob.born(src, w, rec, dm, dt=dt)
+    # finite difference in m = 1/vp^2
+    m = 1.0 / prob.vp ** 2
+    errs = []
+    for eps in (1e-2, 1e-3):
+        d1, _ = prob.forward(src, w, rec, dt=dt, vp=1.0 / np.sqrt(m + eps * dm))
+        errs.append(np.linalg.norm((d1 - d0) / eps - lin) / np.linalg.norm(lin))
+    print("born linearisation errors", errs)
+    assert errs[1] < 0.2 * errs[0] and errs[1] < 5e-3
+    # adjoint pair
+    r = rng.standard_normal(lin.shape) * (np.arange(nt)[:, None] > 2)
+    g = prob.gradient(rec, r, u, dt=dt)
+    lhs, rhs = float(np.sum(lin * r)), float(np.sum(g * dm))
+    print("<J dm, r> =", lhs, " <dm, J^T r> =", rhs)
+    assert abs(lhs - rhs) <= 1e-9 * max(abs(lhs), abs(rhs))
