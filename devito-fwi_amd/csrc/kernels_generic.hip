@@ -15,6 +15,39 @@
 
 namespace mifwi {
 
+// plain star stencil L(f) at the point f points to
+template <typename T, int R, int ND>
+__device__ inline T star(const StepConsts<T> &k, const T *f)
+{
+    T lap = k.c0 * f[0];
+#pragma unroll
+    for (int j = 1; j <= R; ++j) lap += k.c[2][j] * (f[-j] + f[j]);
+    if (ND >= 2) {
+#pragma unroll
+        for (int j = 1; j <= R; ++j) lap += k.c[1][j] * (f[-j * k.s1] + f[j * k.s1]);
+    }
+    if (ND >= 3) {
+#pragma unroll
+        for (int j = 1; j <= R; ++j) lap += k.c[0][j] * (f[-j * k.s0] + f[j * k.s0]);
+    }
+    return lap;
+}
+
+template <typename T, int R, int ND>
+__global__ __launch_bounds__(256) void lap_scale_kernel(StepConsts<T> k, const T *in, long in_shot_stride,
+                                                        const T *m, int power, T *out, long out_shot_stride)
+{
+    const int i2 = blockIdx.x * 64 + threadIdx.x;
+    const int i1 = blockIdx.y * 4 + threadIdx.y;
+    const int shot = blockIdx.z / k.n0;
+    const int i0 = blockIdx.z - shot * k.n0;
+    if (i2 >= k.n2 || i1 >= k.n1) return;
+    const long p = k.off0 + (long)i0 * k.s0 + (long)i1 * k.s1 + i2;
+    const T lap = star<T, R, ND>(k, in + (long)shot * in_shot_stride + p);
+    const T mz = m[p];
+    out[(long)shot * out_shot_stride + p] = power == 1 ? lap / mz : lap / (mz * mz);
+}
+
 template <typename T, int R, int ND, bool GRAD>
 __global__ __launch_bounds__(256) void step_generic_kernel(StepConsts<T> k, StepPtrs<T> sp, GradPtrs<T> gp)
 {
@@ -48,6 +81,7 @@ __global__ __launch_bounds__(256) void step_generic_kernel(StepConsts<T> k, Step
 #pragma unroll
         for (int j = 1; j <= R; ++j) lap += k.c[0][j] * (cur[-j * k.s0] + cur[j * k.s0]);
     }
+    if (sp.ot4) lap += k.dt2 / T(12) * star<T, R, ND>(k, sp.ot4 + (long)shot * k.field + p);
     const T mz = sp.m[p];
     const T ed = sp.eta[p] * k.dt;
     const T uo = sp.old[(long)shot * sp.shot_stride + p];
@@ -56,7 +90,9 @@ __global__ __launch_bounds__(256) void step_generic_kernel(StepConsts<T> k, Step
         const long q = (long)shot * gp.u_shot_stride + p;
         const T um = gp.um[q], u0 = gp.uc[q], up = gp.up[q];
         const long g = (long)shot * gp.g_shot_stride + p;
-        gp.grad[g] += -((um - T(2) * u0 + up) * k.inv_dt2) * uc;
+        T utt = (um - T(2) * u0 + up) * k.inv_dt2;
+        if (gp.bih) utt += k.dt2 / T(12) * star<T, R, ND>(k, gp.bih + (long)shot * k.field + p);
+        gp.grad[g] += -utt * uc;
         if (gp.illum) {
             T add = u0 * u0;
             if (gp.first) add += up * up;
@@ -78,6 +114,48 @@ static int launch_step_rnd(const Plan &p, const StepConsts<T> &k, const StepPtrs
     MIFWI_HIP(hipGetLastError());
     return MIFWI_OK;
 }
+
+template <typename T, int R>
+static int launch_lap_r(const Plan &p, const StepConsts<T> &k, const T *in, long is, int power, T *out, long os,
+                        int nshots)
+{
+    dim3 block(64, 4, 1);
+    dim3 grid((k.n2 + 63) / 64, (k.n1 + 3) / 4, (unsigned)(nshots * k.n0));
+    const T *m = (const T *)p.m;
+    switch (p.L.ndim) {
+        case 1: hipLaunchKernelGGL((lap_scale_kernel<T, R, 1>), grid, block, 0, p.stream, k, in, is, m, power, out, os); break;
+        case 2: hipLaunchKernelGGL((lap_scale_kernel<T, R, 2>), grid, block, 0, p.stream, k, in, is, m, power, out, os); break;
+        default: hipLaunchKernelGGL((lap_scale_kernel<T, R, 3>), grid, block, 0, p.stream, k, in, is, m, power, out, os);
+    }
+    MIFWI_HIP(hipGetLastError());
+    return MIFWI_OK;
+}
+
+template <typename T>
+int launch_lap_scale(const Plan &p, const StepConsts<T> &k, const T *in, long in_shot_stride, int power, T *out,
+                     long out_shot_stride, int nshots)
+{
+    if ((long)nshots * k.n0 > 65535) {
+        set_error("generic kernel: nshots * shape[0] exceeds the grid z limit");
+        return MIFWI_EINVAL;
+    }
+    switch (p.L.R) {
+        case 1: return launch_lap_r<T, 1>(p, k, in, in_shot_stride, power, out, out_shot_stride, nshots);
+        case 2: return launch_lap_r<T, 2>(p, k, in, in_shot_stride, power, out, out_shot_stride, nshots);
+        case 3: return launch_lap_r<T, 3>(p, k, in, in_shot_stride, power, out, out_shot_stride, nshots);
+        case 4: return launch_lap_r<T, 4>(p, k, in, in_shot_stride, power, out, out_shot_stride, nshots);
+        case 5: return launch_lap_r<T, 5>(p, k, in, in_shot_stride, power, out, out_shot_stride, nshots);
+        case 6: return launch_lap_r<T, 6>(p, k, in, in_shot_stride, power, out, out_shot_stride, nshots);
+        case 7: return launch_lap_r<T, 7>(p, k, in, in_shot_stride, power, out, out_shot_stride, nshots);
+        case 8: return launch_lap_r<T, 8>(p, k, in, in_shot_stride, power, out, out_shot_stride, nshots);
+    }
+    set_error("unsupported stencil radius");
+    return MIFWI_EINVAL;
+}
+template int launch_lap_scale<float>(const Plan &, const StepConsts<float> &, const float *, long, int, float *, long,
+                                     int);
+template int launch_lap_scale<double>(const Plan &, const StepConsts<double> &, const double *, long, int, double *,
+                                      long, int);
 
 template <typename T, int R>
 static int launch_step_r(const Plan &p, const StepConsts<T> &k, const StepPtrs<T> &sp, const GradPtrs<T> &gp,

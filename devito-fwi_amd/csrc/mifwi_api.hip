@@ -159,6 +159,9 @@ static void destroy(Plan *p)
     dev_free(p->d_srca);
     dev_free(p->d_grad);
     dev_free(p->d_illum);
+    dev_free(p->d_dm);
+    dev_free(p->d_t4);
+    dev_free(p->d_w2);
     dev_free(p->d_dense);
     dev_free(p->d_partial);
     dev_free(p->d_fval);
@@ -400,6 +403,8 @@ static int validate(const mifwi_config &c)
     if (c.dtype != MIFWI_F32 && c.dtype != MIFWI_F64) return fail(MIFWI_EINVAL, "dtype must be MIFWI_F32 or MIFWI_F64");
     if (c.nsrc < 0 || c.nrec < 0) return fail(MIFWI_EINVAL, "nsrc/nrec must be non-negative");
     if (c.max_shots < 1) return fail(MIFWI_EINVAL, "max_shots must be at least 1");
+    if ((c.flags & MIFWI_FLAG_OT4) && (c.flags & MIFWI_FLAG_FREE_SURFACE))
+        return fail(MIFWI_EINVAL, "the OT4 kernel is not available with a free surface");
     return MIFWI_OK;
 }
 
@@ -427,7 +432,7 @@ static int create(const mifwi_config *cfg, mifwi_plan **out)
         delete p;
         return fail(MIFWI_EINVAL, "grid too large for 32-bit sparse offsets");
     }
-    if (cfg->ndim == 2 && cfg->dtype == MIFWI_F32 && !(cfg->flags & MIFWI_FLAG_GENERIC)) {
+    if (cfg->ndim == 2 && cfg->dtype == MIFWI_F32 && !(cfg->flags & (MIFWI_FLAG_GENERIC | MIFWI_FLAG_OT4))) {
         // tiled fast path: pick the tile shape that wastes fewer threads on this grid
         const int n1 = p->L.n[1], n2 = p->L.n[2];
         auto waste = [&](int tx, int tz) { return (double)((n1 + tx - 1) / tx * tx) * ((n2 + tz - 1) / tz * tz); };
@@ -437,7 +442,7 @@ static int create(const mifwi_config *cfg, mifwi_plan **out)
         p->ntx = (n1 + p->tile_tx - 1) / p->tile_tx;
         p->ntz = (n2 + p->tile_tz - 1) / p->tile_tz;
     }
-    if (cfg->ndim == 3 && cfg->dtype == MIFWI_F32 && !(cfg->flags & MIFWI_FLAG_GENERIC)) {
+    if (cfg->ndim == 3 && cfg->dtype == MIFWI_F32 && !(cfg->flags & (MIFWI_FLAG_GENERIC | MIFWI_FLAG_OT4))) {
         // 2.5-D fast path: 16 x 64 tiles of the (y, z) plane, x split into chunks so that one launch
         // offers several blocks per CU
         p->kind = 2;
@@ -468,6 +473,10 @@ static int create(const mifwi_config *cfg, mifwi_plan **out)
     if ((rc = dev_alloc(*p, &p->eta, field * es, true))) return bail(rc);
     if ((rc = dev_alloc(*p, &p->rot_u, S * 3 * field * es, true))) return bail(rc);
     if ((rc = dev_alloc(*p, &p->rot_v, S * 3 * field * es, true))) return bail(rc);
+    if (cfg->flags & MIFWI_FLAG_OT4) {
+        if ((rc = dev_alloc(*p, &p->d_t4, S * field * es, true))) return bail(rc);
+        if ((rc = dev_alloc(*p, &p->d_w2, S * field * es, true))) return bail(rc);
+    }
     if ((rc = dev_alloc(*p, &p->d_wavelet, S * nt * std::max(1, cfg->nsrc) * es, true))) return bail(rc);
     if ((rc = dev_alloc(*p, &p->d_srca, S * nt * std::max(1, cfg->nsrc) * es, true))) return bail(rc);
     if ((rc = dev_alloc(*p, &p->d_rec, S * nt * std::max(1, cfg->nrec) * es, true))) return bail(rc);
@@ -753,8 +762,13 @@ static int forward_step(Plan &p, const LoopCtx<T> &c, const T *cur, const T *old
         launches += 1;
         return MIFWI_OK;
     }
-    StepPtrs<T> sp{cur, old, out, shot_stride, (const T *)p.m, (const T *)p.eta};
+    StepPtrs<T> sp{cur, old, out, shot_stride, (const T *)p.m, (const T *)p.eta, nullptr};
     GradPtrs<T> gp{};
+    if (p.cfg.flags & MIFWI_FLAG_OT4) {
+        if ((rc = launch_lap_scale<T>(p, c.k, cur, shot_stride, 1, (T *)p.d_t4, p.L.field, c.nshots))) return rc;
+        sp.ot4 = (const T *)p.d_t4;
+        launches += 1;
+    }
     if ((rc = launch_step_generic<T>(p, c.k, sp, gp, c.nshots))) return rc;
     SparsePtrs<T> q{};
     if (inject) {
@@ -823,7 +837,7 @@ static int backward_step(Plan &p, const LoopCtx<T> &c, const T *cur, const T *ol
         launches += 1;
         return MIFWI_OK;
     }
-    StepPtrs<T> sp{cur, old, out, shot_stride, (const T *)p.m, (const T *)p.eta};
+    StepPtrs<T> sp{cur, old, out, shot_stride, (const T *)p.m, (const T *)p.eta, nullptr};
     GradPtrs<T> gp{};
     if (with_grad) {
         gp.um = um, gp.uc = u0, gp.up = up;
@@ -832,6 +846,16 @@ static int backward_step(Plan &p, const LoopCtx<T> &c, const T *cur, const T *ol
         gp.illum = with_illum ? (T *)p.d_illum : nullptr;
         gp.g_shot_stride = p.L.field;
         gp.first = first;
+    }
+    if (p.cfg.flags & MIFWI_FLAG_OT4) {
+        if ((rc = launch_lap_scale<T>(p, c.k, cur, shot_stride, 1, (T *)p.d_t4, p.L.field, c.nshots))) return rc;
+        sp.ot4 = (const T *)p.d_t4;
+        launches += 1;
+        if (with_grad) {
+            if ((rc = launch_lap_scale<T>(p, c.k, u0, u_stride, 2, (T *)p.d_w2, p.L.field, c.nshots))) return rc;
+            gp.bih = (const T *)p.d_w2;
+            launches += 1;
+        }
     }
     if ((rc = launch_step_generic<T>(p, c.k, sp, gp, c.nshots))) return rc;
     SparsePtrs<T> q{};

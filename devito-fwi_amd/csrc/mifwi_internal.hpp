@@ -118,6 +118,7 @@ struct Plan {
     void *d_res = nullptr;                   // [max_shots][nt][nrec]   adjoint source / residual
     void *d_srca = nullptr;                  // [max_shots][nt][nsrc]
     void *d_grad = nullptr, *d_illum = nullptr; // [max_shots][field] haloed accumulators
+    void *d_t4 = nullptr, *d_w2 = nullptr;   // OT4 scratch fields, [max_shots][field] each
     void *d_dm = nullptr;                    // [field] haloed model perturbation of the Born operator
     void *d_dense = nullptr;                 // dense staging, max(max_shots*ngrid, ...) elements
     size_t dense_elems = 0;
@@ -161,6 +162,7 @@ struct StepPtrs {
     T *out;           // level being produced                         (shot 0)
     long shot_stride; // elements between consecutive shots
     const T *m, *eta;
+    const T *ot4;     // OT4: (1/m) L(cur) per shot, [shots][field]; null for OT2
 };
 
 template <typename T>
@@ -171,6 +173,7 @@ struct GradPtrs {
     T *illum;              // or null
     long g_shot_stride;
     int first;             // 1 on the first backward step: also add u[time+1]^2 to illum
+    const T *bih;          // OT4: m^-2 L(u[time]) per shot, [shots][field]; null for OT2
 };
 
 template <typename T>
@@ -195,6 +198,12 @@ struct SparsePtrs {
 };
 template <typename T>
 int launch_sparse(const Plan &p, const SparsePtrs<T> &sp, int nshots);
+
+// out[shot] = L(in[shot]) / m^power on the grid points (halo untouched, i.e. zero): the inner half of
+// the OT4 biharmonic terms (seismic/acoustic/operators.py:55,219).
+template <typename T>
+int launch_lap_scale(const Plan &p, const StepConsts<T> &k, const T *in, long in_shot_stride, int power, T *out,
+                     long out_shot_stride, int nshots);
 
 // Born source term of one step (seismic/acoustic/operators.py:263): for every grid point
 //   U_out += dt^2 * ( -dm * (u_new - 2 u_cur + u_old) / dt^2 ) / ( m + eta dt )

@@ -2,8 +2,8 @@
 `AcousticWaveSolver` with the call signatures of the reference's
 seismic/acoustic/wavesolver.py:10-246, executing on an MI355X through libmifwi instead of
 through Devito-generated C.  forward / adjoint / jacobian (alias born) / jacobian_adjoint (alias
-gradient) are implemented, with or without a free surface; the OT4 kernel and the pyrevolve
-`checkpointing=True` keyword are not part of this package and raise.
+gradient) are implemented for the OT2 and OT4 kernels; OT2 also with a free surface.  The
+pyrevolve `checkpointing=True` keyword is not part of this package and raises.
 """
 import numpy as np
 
@@ -50,8 +50,10 @@ class AcousticWaveSolver(object):
         self.model._initialize_bcs(bcs="damp")
         self.geometry = geometry
         assert self.model.grid == geometry.grid
-        if kernel != 'OT2':
-            raise NotImplementedError("only the OT2 (2nd order in time) kernel is implemented")
+        if kernel not in ('OT2', 'OT4'):
+            raise ValueError("Unrecognized kernel")
+        if kernel == 'OT4' and getattr(model, 'fs', False):
+            raise NotImplementedError("the OT4 kernel is not available with a free surface")
         self.space_order = space_order
         self.kernel = kernel
         self._device = kwargs.pop('device', -1)
@@ -59,16 +61,19 @@ class AcousticWaveSolver(object):
 
     @property
     def dt(self):
+        # wavesolver.py:41-46: the 4th-order kernel steps sqrt(3) ~ 1.73 times further
+        if self.kernel == 'OT4':
+            return self.model.dtype(1.73 * self.model.critical_dt)
         return self.model.critical_dt
 
     # -- plumbing -----------------------------------------------------------------------------
     def _entry(self, dt, nsrc, nrec, nt):
         from mifwi import engine
         m = self.model
-        from mifwi import FLAG_FREE_SURFACE
+        from mifwi import FLAG_FREE_SURFACE, FLAG_OT4
+        flags = (FLAG_FREE_SURFACE if getattr(m, 'fs', False) else 0) | (FLAG_OT4 if self.kernel == 'OT4' else 0)
         return engine.get_plan(m.grid.shape, m.spacing, m.grid.origin, self.space_order, nt, dt, nsrc, nrec,
-                               max_shots=1, dtype=m.dtype, device=self._device,
-                               flags=FLAG_FREE_SURFACE if getattr(m, 'fs', False) else 0)
+                               max_shots=1, dtype=m.dtype, device=self._device, flags=flags)
 
     def _damp_array(self):
         d = self.model.damp

@@ -59,10 +59,15 @@ enum {
     MIFWI_FLAG_GENERIC = 4,      /* force the untiled reference kernels                    */
     MIFWI_FLAG_CHECKPOINT = 8,   /* keep the forward wavefield as checkpoints + recomputation
                                     even when every level would fit (automatic otherwise)  */
-    MIFWI_FLAG_FREE_SURFACE = 16 /* free surface at the low end of the LAST dimension: the model was
+    MIFWI_FLAG_FREE_SURFACE = 16, /* free surface at the low end of the LAST dimension: the model was
                                     built with fs=True (seismic/model.py:100-110,157: no absorbing
                                     layer there) and the stencil mirrors the field antisymmetrically
                                     about index 0 (seismic/acoustic/operators.py:8-35,92-94)   */
+    MIFWI_FLAG_OT4 = 32          /* 4th-order-in-time kernel: Laplacian + dt^2/12 * biharmonic(1/m)
+                                    and the matching gradient term (seismic/acoustic/operators.py:
+                                    38-56,216-219); runs on the untiled kernels; not combinable with
+                                    MIFWI_FLAG_FREE_SURFACE.  The caller passes dt = 1.73 * CFL dt as
+                                    the reference's solver does (wavesolver.py:41-46).             */
 };
 
 typedef struct mifwi_plan mifwi_plan; /* opaque */

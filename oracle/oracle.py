@@ -141,7 +141,7 @@ class Problem(object):
     """
 
     def __init__(self, vp, spacing, nbl, space_order, origin=None, dtype=np.float32, dt=None,
-                 model_space_order=None, fs=False):
+                 model_space_order=None, fs=False, kernel='OT2'):
         self.dtype = np.dtype(dtype)
         vp = np.asarray(vp, dtype=self.dtype)
         self.ndim = vp.ndim
@@ -154,6 +154,9 @@ class Problem(object):
         self.user_dt = dt
         # model.py:100: origin_pml = dtype(o - s*nbl)
         self.fs = bool(fs)
+        assert kernel in ('OT2', 'OT4')
+        self.ot4 = int(kernel == 'OT4')
+        assert not (self.ot4 and self.fs), 'OT4 with a free surface is not restated'
         origin_pad = [float(self.dtype.type(o - s * self.nbl)) for o, s in zip(self.origin, self.spacing)]
         shape_pad = [s + 2 * self.nbl for s in self.shape]
         if self.fs:                                   # model.py:106-110
@@ -171,6 +174,11 @@ class Problem(object):
             self.vp = np.ascontiguousarray(vp)
         else:
             raise ValueError("bad vp shape %s" % (vp.shape,))
+
+    @property
+    def solver_dt(self):
+        """Time step the solver uses: 1.73 x critical_dt for OT4 (wavesolver.py:41-46)."""
+        return self.dtype.type(1.73 * self.critical_dt) if self.ot4 else self.critical_dt
 
     @property
     def critical_dt(self):
@@ -192,7 +200,7 @@ class Problem(object):
         fn = getattr(lib(), "oracle_forward_" + _sfx(self.dtype))
         rc = fn(self.ndim, _ia(self.shape_pad), _da(self.spacing), _da(self.origin_pad), self.space_order,
                 nt, ctypes.c_double(dt), _p(vp), _p(self.damp), sc.shape[0], _p(sc), _p(w),
-                rc_.shape[0], _p(rc_), _p(rec), _p(u), _p(ul), int(self.fs))
+                rc_.shape[0], _p(rc_), _p(rec), _p(u), _p(ul), int(self.fs), self.ot4)
         assert rc == 0, rc
         out = (rec, u)
         return out + (ul,) if return_last else out
@@ -208,7 +216,7 @@ class Problem(object):
         fn = getattr(lib(), "oracle_adjoint_" + _sfx(self.dtype))
         rc = fn(self.ndim, _ia(self.shape_pad), _da(self.spacing), _da(self.origin_pad), self.space_order,
                 nt, ctypes.c_double(dt), _p(vp), _p(self.damp), sc.shape[0], _p(sc), _p(srca),
-                rc_.shape[0], _p(rc_), _p(rec), None, int(self.fs))
+                rc_.shape[0], _p(rc_), _p(rec), None, int(self.fs), self.ot4)
         assert rc == 0, rc
         return srca
 
@@ -227,7 +235,7 @@ class Problem(object):
         fn = getattr(lib(), "oracle_gradient_" + _sfx(self.dtype))
         rc = fn(self.ndim, _ia(self.shape_pad), _da(self.spacing), _da(self.origin_pad), self.space_order,
                 nt, ctypes.c_double(dt), _p(vp), _p(self.damp), rc_.shape[0], _p(rc_), _p(residual),
-                _p(u), _p(grad), int(self.fs))
+                _p(u), _p(grad), int(self.fs), self.ot4)
         assert rc == 0, rc
         return grad
 

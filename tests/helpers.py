@@ -26,13 +26,14 @@ class Case(object):
     """A small acquisition: oracle problem + geometry + wavelet, all seeded."""
 
     def __init__(self, shape, spacing, nbl, space_order, nt=None, tn=None, nshots=2, nrec=11, nsrc=1,
-                 dtype=np.float32, seed=0, f0=0.015, vp=None, fs=False):
+                 dtype=np.float32, seed=0, f0=0.015, vp=None, fs=False, kernel='OT2'):
         self.dtype = np.dtype(dtype)
         self.ndim = len(shape)
         vp = smooth_random_vp(shape, seed=seed) if vp is None else vp
         self.fs = bool(fs)
-        self.prob = orc.Problem(vp.astype(self.dtype), spacing, nbl, space_order, dtype=self.dtype, fs=fs)
-        self.dt = float(self.prob.critical_dt)
+        self.prob = orc.Problem(vp.astype(self.dtype), spacing, nbl, space_order, dtype=self.dtype, fs=fs,
+                                kernel=kernel)
+        self.dt = float(self.prob.solver_dt)
         if nt is None:
             nt, tv = orc.time_axis(0.0, tn, self.dt)
         else:
@@ -57,7 +58,7 @@ class Case(object):
         p = self.prob
         plan = mifwi.Plan(p.shape_pad, p.spacing, p.origin_pad, p.space_order, self.nt, self.dt, self.nsrc,
                           self.nrec, max_shots=max_shots or self.nshots, dtype=self.dtype,
-                          flags=flags | (16 if self.fs else 0))
+                          flags=flags | (16 if self.fs else 0) | (32 if self.prob.ot4 else 0))
         plan.set_model(p.vp, p.damp)
         plan.set_geometry(self.src, self.rec)
         return plan

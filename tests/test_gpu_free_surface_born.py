@@ -157,3 +157,37 @@ def test_solver_jacobian_matches_oracle():
     assert rel_l2(rec.data, ref) <= 1e-4
     assert U.data.shape == (3,) + model.grid.shape and np.abs(U.data).max() > 0
     assert summary.gpointss > 0
+
+
+# ---- OT4 kernel (operators.py:38-56,216-219): no number of the reference pins it (its own test,
+# acoustic_example.py:66-72, checks finiteness only), so parity is against the restatement alone.
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("so", [4, 8])
+def test_2d_ot4(mifwi, so, dtype):
+    _check_case(mifwi, Case((45, 38), (10.0, 12.5), nbl=9, space_order=so, nt=110, nshots=2, nrec=13,
+                            kernel='OT4', dtype=dtype))
+
+
+def test_3d_ot4(mifwi):
+    _check_case(mifwi, Case((20, 23, 30), (10.0, 10.0, 10.0), nbl=5, space_order=4, nt=40, nshots=1, nrec=9,
+                            kernel='OT4', seed=8))
+
+
+def test_ot4_stability_and_solver_dt():
+    """acoustic_example.py:66-72: tiny grid, no absorbing layer, tn = 20000, OT4: finite records;
+    the solver steps with 1.73 x the CFL time step (wavesolver.py:41-46)."""
+    from seismic import demo_model, setup_geometry
+    from seismic.acoustic import AcousticWaveSolver
+    for ndim in (1, 2, 3):
+        model = demo_model('layers-isotropic', space_order=4, shape=(11,) * ndim, nbl=0, dtype=np.float32,
+                           spacing=(20.0,) * ndim)
+        geometry = setup_geometry(model, 20000.0)
+        solver = AcousticWaveSolver(model, geometry, kernel='OT4', space_order=4)
+        assert np.isclose(float(solver.dt), 1.73 * float(model.critical_dt), rtol=1e-6)
+        rec, _, _ = solver.forward(save=False)
+        assert np.isfinite(np.linalg.norm(rec.data))
+
+
+def test_ot4_free_surface_rejected(mifwi):
+    with pytest.raises(mifwi.MifwiError):
+        mifwi.Plan((20, 20), (10.0, 10.0), (0.0, 0.0), 4, 10, 1.0, 1, 1, flags=16 | 32)
