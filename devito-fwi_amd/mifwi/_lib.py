@@ -59,6 +59,13 @@ def load_library():
     if not os.path.exists(path):
         raise ImportError("libmifwi.so not found at %s: build it with `make -C devito-fwi_amd/csrc` "
                           "(there is no CPU fallback)" % path)
+    # PyTorch wheels carry their own HIP runtime.  When this library is loaded first, the system
+    # runtime it links against is the one the process keeps, and torch then fails to see any GPU;
+    # loading torch's runtime first works for both.  torch is optional for the C ABI itself.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = ctypes.CDLL(path)
     vp = ctypes.c_void_p
     i32 = ctypes.c_int32
