@@ -91,8 +91,11 @@ __device__ inline void lds_stv(float *p, const float (&d)[V])
 // at radius 8 that is 165 without spilling and worth +8 % over 2 blocks), the gradient variant,
 // which carries five more vectors, to 2 blocks per CU.
 // GRAD: also accumulate the FWI gradient.  ISO: equal spacing in x, y and z (one coefficient set).
+#ifndef MIFWI_3D_GRAD_WAVES
+#define MIFWI_3D_GRAD_WAVES 2
+#endif
 template <int R, int TY, int TZ, int V, bool GRAD, bool ISO>
-__global__ __launch_bounds__(TY *TZ / V, (GRAD ? 2 : 3) * (TY * TZ / V) / 256) void step3d_kernel(Step3DArgs a)
+__global__ __launch_bounds__(TY *TZ / V, (GRAD ? MIFWI_3D_GRAD_WAVES : 3) * (TY * TZ / V) / 256) void step3d_kernel(Step3DArgs a)
 {
     constexpr int NT = TY * TZ / V;                     // threads per block
     constexpr int RZ = (R + 3) / 4 * 4;
