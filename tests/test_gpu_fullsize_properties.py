@@ -1,0 +1,102 @@
+"""
+Size-independent properties at the full benchmark sizes, where the CPU oracle is too slow to be
+the checker: the discrete forward and adjoint propagators are an adjoint pair
+(<F s, r> = <s, F^T r>, reference seismic/acoustic/operators.py:98-180), forward modelling is
+linear in the wavelet, and the checkpointed gradient equals the fully saved one bit for bit.
+
+Sizes: the 3-D north-star grid 512^3 + 2*40 = 592^3 at space order 16 (and 8), and Marmousi-II
+(420 x 220 padded, nt = 1501, 8 shots, space order 16).
+Tolerance of the float32 adjoint test: 2e-5 relative in 3-D (measured 7.7e-6 at order 16, 1.4e-6 at
+order 8), 1e-5 for Marmousi-II (the float64 pair agrees to 1e-15 on small grids; float32 accumulates
+rounding over the time loop and the random test vectors cancel heavily in the inner products).
+"""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def mifwi():
+    import mifwi as m
+    return m
+
+
+def _dot(a, b):
+    return float(np.sum(a.astype(np.float64) * b.astype(np.float64)))
+
+
+@pytest.mark.parametrize("so", [16, 8])
+def test_3d_full_grid_adjoint_pair_and_linearity(mifwi, so):
+    from seismic import Model
+    n, nbl, nt = 512, 40, 48
+    vp = np.empty((n, n, n), dtype=np.float32)
+    vp[:] = np.linspace(1.5, 4.5, n, dtype=np.float32)[None, None, :]
+    vp += 0.2 * np.sin(np.arange(n, dtype=np.float32) * 0.05)[:, None, None]
+    model = Model(origin=(0., 0., 0.), spacing=(10., 10., 10.), shape=vp.shape, space_order=so, vp=vp, nbl=nbl,
+                  bcs="damp")
+    del vp
+    dt = float(model.critical_dt)
+    sp = model.grid.shape
+    assert sp == (592, 592, 592)
+    rng = np.random.default_rng(7)
+    nsrc, nrec = 3, 200
+    src = (rng.random((1, nsrc, 3)) * 0.5 + 0.25).astype(np.float32) * 5110.0
+    rec = (rng.random((nrec, 3)) * 0.5 + 0.25).astype(np.float32) * 5110.0
+    # keep sources and receivers within reach of each other in nt steps
+    rec = (src[0, 0] + (rec - 2555.0) * 0.06).astype(np.float32)
+    src[0, 1:] = src[0, 0] + np.array([[55.0, -32.0, 41.0], [-61.0, 17.0, -23.0]], dtype=np.float32)
+    plan = mifwi.Plan(sp, model.spacing, model.grid.origin, so, nt, dt, nsrc, nrec, max_shots=1)
+    plan.set_model(model.vp.data, model.damp.data)
+    plan.set_geometry(src, rec)
+    s = rng.standard_normal((nt, nsrc)).astype(np.float32)
+    r = rng.standard_normal((1, nt, nrec)).astype(np.float32)
+    fs = plan.forward(s)
+    assert np.abs(fs).max() > 0
+    ftr = plan.adjoint(r)
+    lhs, rhs = _dot(fs, r), _dot(s, ftr[0])
+    print("3-D so=%d: <Fs,r> = %.9e  <s,F^T r> = %.9e" % (so, lhs, rhs))
+    assert abs(lhs - rhs) <= 2e-5 * max(abs(lhs), abs(rhs))
+    # linearity in the wavelet
+    f2 = plan.forward(2.0 * s)
+    assert np.linalg.norm((f2 - 2.0 * fs).ravel()) <= 1e-6 * np.linalg.norm(fs.ravel())
+    plan.close()
+
+
+def test_marmousi2_full_adjoint_pair_and_checkpoint_identity(mifwi):
+    from seismic import Model
+    shape, nbl, so = (340, 140), 40, 16
+    data = os.path.join(ROOT, "tests", "golden", "model_data", "SMARM2")
+    vp = np.fromfile(os.path.join(data, "vp.smooth_20"), dtype=np.float32).reshape(shape) / 1000
+    model = Model(origin=(0, 0), spacing=(25., 25.), shape=shape, space_order=so, vp=vp, nbl=nbl, dt=3.0)
+    dt, nt, nshots, nrec = 3.0, 1501, 8, 340
+    src = np.empty((nshots, 1, 2), dtype=np.float32)
+    src[:, 0, 0] = np.linspace(0, model.domain_size[0], nshots)
+    src[:, 0, 1] = 50.0
+    rec = np.empty((nrec, 2), dtype=np.float32)
+    rec[:, 0] = np.linspace(25.0, model.domain_size[0] - 25.0, nrec)
+    rec[:, 1] = 50.0
+    rng = np.random.default_rng(11)
+    s = rng.standard_normal((nshots, nt, 1)).astype(np.float32)
+    r = rng.standard_normal((nshots, nt, nrec)).astype(np.float32)
+    out = {}
+    for name, flags in (("full", 0), ("ckpt", mifwi.FLAG_CHECKPOINT)):
+        plan = mifwi.Plan(model.grid.shape, model.spacing, model.grid.origin, so, nt, dt, 1, nrec, max_shots=nshots,
+                          flags=flags)
+        plan.set_model(model.vp.data, model.damp.data)
+        plan.set_geometry(src, rec)
+        if name == "full":
+            fs = plan.forward(s, wavelet_per_shot=True)
+            ftr = plan.adjoint(r)
+            for k in range(nshots):
+                lhs, rhs = _dot(fs[k], r[k]), _dot(s[k], ftr[k])
+                assert abs(lhs - rhs) <= 1e-5 * max(abs(lhs), abs(rhs)), (k, lhs, rhs)
+        plan.forward(s, wavelet_per_shot=True, save=True)
+        out[name] = plan.gradient(r, want_illum=True)
+        plan.close()
+    assert np.array_equal(out["full"][0], out["ckpt"][0])
+    assert np.array_equal(out["full"][1], out["ckpt"][1])
