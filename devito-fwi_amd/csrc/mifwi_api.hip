@@ -160,6 +160,10 @@ static void destroy(Plan *p)
     dev_free(p->d_grad);
     dev_free(p->d_illum);
     dev_free(p->d_dm);
+    dev_free(p->tti_par);
+    dev_free(p->tti_fwd);
+    dev_free(p->tti_adj);
+    dev_free(p->tti_tmp);
     dev_free(p->d_t4);
     dev_free(p->d_w2);
     dev_free(p->d_dense);
@@ -1229,6 +1233,144 @@ static int l2_misfit_gradient(Plan &p, int nshots, const void *wavelet, int per_
     return finish(p);
 }
 
+// ---- TTI ---------------------------------------------------------------------------------------
+template <typename T>
+static int tti_set_model(Plan &p, const void *eps, const void *delta, const void *theta, const void *phi)
+{
+    if (p.cfg.ndim < 2) return fail(MIFWI_EINVAL, "TTI needs a 2-D or 3-D grid");
+    if (p.cfg.space_order % 4) return fail(MIFWI_EINVAL, "TTI needs space_order divisible by 4");
+    if (p.cfg.flags & (MIFWI_FLAG_FREE_SURFACE | MIFWI_FLAG_OT4))
+        return fail(MIFWI_EINVAL, "TTI is not available with a free surface or the OT4 kernel");
+    if (!eps || !delta || !theta) return fail(MIFWI_EINVAL, "epsilon, delta and theta are required");
+    int rc;
+    const size_t fb = (size_t)p.L.field * sizeof(T), S = (size_t)p.cfg.max_shots;
+    if (!p.tti_par) {
+        if ((rc = dev_alloc(p, &p.tti_par, 6 * fb, true))) return rc;
+        if ((rc = dev_alloc(p, &p.tti_fwd, 2 * S * 3 * fb, true))) return rc;
+        if ((rc = dev_alloc(p, &p.tti_adj, 2 * S * 3 * fb, true))) return rc;
+        if ((rc = dev_alloc(p, &p.tti_tmp, 5 * S * fb, true))) return rc;
+    }
+    const StepConsts<T> k = make_consts<T>(p);
+    T *par = (T *)p.tti_par;
+    T *dense = (T *)p.d_dense;
+    const size_t gb = (size_t)p.L.ngrid * sizeof(T);
+    // field order: et, dl, ct, st, cp, sp
+    struct { const void *src; int mode; T halo; } spec[6] = {{eps, 1, T(1)},   {delta, 2, T(1)}, {theta, 3, T(1)},
+                                                              {theta, 4, T(0)}, {phi, 3, T(1)},   {phi, 4, T(0)}};
+    for (int f = 0; f < 6; ++f) {
+        const T *src = nullptr;
+        if (spec[f].src) {
+            if ((rc = copy_any(p, dense, spec[f].src, gb))) return rc;
+            src = dense;
+        }
+        if ((rc = launch_tti_param<T>(p, k, src, par + (long)f * p.L.field, spec[f].mode, spec[f].halo))) return rc;
+    }
+    p.tti_fwd_valid = p.tti_adj_valid = false;
+    return finish(p);
+}
+
+template <typename T>
+static TtiParams<T> tti_params(const Plan &p)
+{
+    TtiParams<T> q{};
+    const T *par = (const T *)p.tti_par;
+    q.et = par, q.dl = par + p.L.field, q.ct = par + 2 * p.L.field, q.st = par + 3 * p.L.field;
+    q.cp = par + 4 * p.L.field, q.sp = par + 5 * p.L.field;
+    q.p = p.L.R / 2;
+    for (int j = 1; j <= q.p; ++j) {   // a_j = (-1)^(j+1) (p!)^2 / (j (p-j)! (p+j)!)
+        double num = 1.0, den = (double)j;
+        for (int i = 1; i <= q.p; ++i) num *= (double)i * (double)i;
+        for (int i = 1; i <= q.p - j; ++i) den *= (double)i;
+        for (int i = 1; i <= q.p + j; ++i) den *= (double)i;
+        q.a[j] = (T)((j % 2 ? 1.0 : -1.0) * num / den);
+    }
+    for (int d = 0; d < 3; ++d) q.ih[d] = T(1);
+    for (int d = 0; d < p.cfg.ndim; ++d) q.ih[3 - p.cfg.ndim + d] = (T)(1.0 / p.cfg.spacing[d]);
+    return q;
+}
+
+// mode 0: forward (d_wavelet -> d_rec), mode 1: adjoint (d_res -> d_srca)
+template <typename T>
+static int tti_run(Plan &p, int nshots, int mode)
+{
+    if (!p.tti_par) return fail(MIFWI_ESTATE, "mifwi_tti_set_model has not been called");
+    const Layout &L = p.L;
+    const int nt = p.cfg.nt;
+    const long S = p.cfg.max_shots, stride = 3L * L.field;
+    T *fu = (T *)(mode == 0 ? p.tti_fwd : p.tti_adj);
+    T *fv = fu + S * stride;
+    T *tmp = (T *)p.tti_tmp;
+    T *wA = tmp, *wB = tmp + S * L.field, *gzA = tmp + 2 * S * L.field, *gzB = tmp + 3 * S * L.field,
+      *sum = tmp + 4 * S * L.field;
+    MIFWI_HIP(hipMemsetAsync(fu, 0, (size_t)nshots * stride * sizeof(T), p.stream));
+    MIFWI_HIP(hipMemsetAsync(fv, 0, (size_t)nshots * stride * sizeof(T), p.stream));
+    MIFWI_HIP(hipMemsetAsync(tmp, 0, (size_t)5 * S * L.field * sizeof(T), p.stream));
+    const SparseSet &inj = mode == 0 ? p.src : p.rec, &itp = mode == 0 ? p.rec : p.src;
+    const T *vals_in = (const T *)(mode == 0 ? p.d_wavelet : p.d_res);
+    T *vals_out = (T *)(mode == 0 ? p.d_rec : p.d_srca);
+    MIFWI_HIP(hipMemsetAsync(vals_out, 0, (size_t)nshots * nt * std::max(1, itp.npoint) * sizeof(T), p.stream));
+    const StepConsts<T> k = make_consts<T>(p);
+    const TtiParams<T> q = tti_params<T>(p);
+    auto enqueue = [&](int &launches) -> int {
+        for (int step = 1; step <= nt - 2; ++step) {
+            const int time = mode == 0 ? step : nt - 1 - step;
+            const long c = (long)(time % 3) * L.field;
+            const long nx = (long)((time + (mode == 0 ? 1 : 2)) % 3) * L.field;
+            const long od = (long)((time + (mode == 0 ? 2 : 1)) % 3) * L.field;
+            TtiLevels<T> lv{fu + c, fu + od, fv + c, fv + od, fu + nx, fv + nx, stride};
+            int r;
+            if ((r = launch_tti_step<T>(p, k, q, mode == 0, lv, wA, wB, gzA, gzB, sum, nshots, launches))) return r;
+            SparsePtrs<T> sq{};
+            sq.inj = &inj, sq.field_inj = fu + nx, sq.vals_inj = vals_in;
+            sq.itp = &itp, sq.field_int = sum, sq.vals_out = vals_out;
+            sq.shot_stride = stride;
+            sq.m = (const T *)p.m, sq.time = time, sq.nt = nt, sq.dt2 = k.dt2;
+            // the sampled field (sum) is one level per shot: its own stride
+            SparsePtrs<T> s1 = sq;
+            s1.itp = nullptr;
+            if ((r = launch_sparse<T>(p, s1, nshots))) return r;              // inject into the first field
+            s1.field_inj = fv + nx;
+            if ((r = launch_sparse<T>(p, s1, nshots))) return r;              // ... and into the second
+            SparsePtrs<T> s2 = sq;
+            s2.inj = nullptr;
+            s2.shot_stride = L.field;
+            if ((r = launch_sparse<T>(p, s2, nshots))) return r;              // sample u + v
+            launches += 3;
+        }
+        return MIFWI_OK;
+    };
+    int launches = 0, rc;
+    float ms = 0;
+    const auto key = std::make_tuple(4 + mode, nshots, 0, 0, 0);
+    if ((rc = timed_loop(p, &key, enqueue, launches, ms))) return rc;
+    fill_stats(p, ms, nt - 2, nshots, 2 * 20.0 + 6 * 4.0, launches, mode == 1);
+    (mode == 0 ? p.tti_fwd_valid : p.tti_adj_valid) = true;
+    return MIFWI_OK;
+}
+
+template <typename T>
+static int tti_forward(Plan &p, int nshots, const void *wavelet, int per_shot, void *rec_out)
+{
+    int rc;
+    if ((rc = check_run(p, nshots))) return rc;
+    if ((rc = upload_wavelet<T>(p, nshots, wavelet, per_shot))) return rc;
+    if ((rc = tti_run<T>(p, nshots, 0))) return rc;
+    if (rec_out && (rc = copy_any(p, rec_out, p.d_rec, (size_t)nshots * p.cfg.nt * p.cfg.nrec * sizeof(T)))) return rc;
+    return finish(p);
+}
+
+template <typename T>
+static int tti_adjoint(Plan &p, int nshots, const void *rec_in, void *srca_out)
+{
+    int rc;
+    if ((rc = check_run(p, nshots))) return rc;
+    if (!rec_in) return fail(MIFWI_EINVAL, "rec_in is null");
+    if ((rc = copy_any(p, p.d_res, rec_in, (size_t)nshots * p.cfg.nt * p.cfg.nrec * sizeof(T)))) return rc;
+    if ((rc = tti_run<T>(p, nshots, 1))) return rc;
+    if (srca_out && (rc = copy_any(p, srca_out, p.d_srca, (size_t)nshots * p.cfg.nt * p.cfg.nsrc * sizeof(T)))) return rc;
+    return finish(p);
+}
+
 template <typename T>
 static int read_wavefield(Plan &p, int which, int shot, int first, int count, void *out)
 {
@@ -1247,8 +1389,15 @@ static int read_wavefield(Plan &p, int which, int shot, int first, int count, vo
         if (!(which == 1 ? p.rot_u_valid : p.rot_v_valid)) return fail(MIFWI_ESTATE, "no buffered wavefield available");
         base = (const T *)(which == 1 ? p.rot_u : p.rot_v) + (long)shot * 3 * p.L.field;
         nlev = 3;
+    } else if (which >= 3 && which <= 6) {
+        const bool fwd = which <= 4;
+        if (!(fwd ? p.tti_fwd_valid : p.tti_adj_valid)) return fail(MIFWI_ESTATE, "no TTI wavefield available");
+        const T *pair = (const T *)(fwd ? p.tti_fwd : p.tti_adj);
+        const int second = (which - 3) & 1;
+        base = pair + ((long)second * p.cfg.max_shots + shot) * 3 * p.L.field;
+        nlev = 3;
     } else {
-        return fail(MIFWI_EINVAL, "which must be 0, 1 or 2");
+        return fail(MIFWI_EINVAL, "which must be 0..6");
     }
     if (first < 0 || count < 0 || first + count > nlev) return fail(MIFWI_EINVAL, "level range out of bounds");
     int rc;
@@ -1412,6 +1561,25 @@ int mifwi_l2_misfit_gradient(mifwi_plan *plan, int32_t nshots, const void *wavel
     return DISPATCH(
         l2_misfit_gradient<float>(p, nshots, wavelet, wavelet_per_shot, obs, fval, grad, illum, residual_out, syn_out),
         l2_misfit_gradient<double>(p, nshots, wavelet, wavelet_per_shot, obs, fval, grad, illum, residual_out, syn_out));
+}
+
+int mifwi_tti_set_model(mifwi_plan *plan, const void *epsilon, const void *delta, const void *theta, const void *phi)
+{
+    PLAN_OR_FAIL(plan);
+    return DISPATCH(tti_set_model<float>(p, epsilon, delta, theta, phi), tti_set_model<double>(p, epsilon, delta, theta, phi));
+}
+
+int mifwi_tti_forward(mifwi_plan *plan, int32_t nshots, const void *wavelet, int32_t wavelet_per_shot, void *rec_out)
+{
+    PLAN_OR_FAIL(plan);
+    return DISPATCH(tti_forward<float>(p, nshots, wavelet, wavelet_per_shot, rec_out),
+                    tti_forward<double>(p, nshots, wavelet, wavelet_per_shot, rec_out));
+}
+
+int mifwi_tti_adjoint(mifwi_plan *plan, int32_t nshots, const void *rec_in, void *srca_out)
+{
+    PLAN_OR_FAIL(plan);
+    return DISPATCH(tti_adjoint<float>(p, nshots, rec_in, srca_out), tti_adjoint<double>(p, nshots, rec_in, srca_out));
 }
 
 int mifwi_read_wavefield(mifwi_plan *plan, int32_t which, int32_t shot, int32_t first, int32_t count, void *out)

@@ -119,6 +119,10 @@ struct Plan {
     void *d_srca = nullptr;                  // [max_shots][nt][nsrc]
     void *d_grad = nullptr, *d_illum = nullptr; // [max_shots][field] haloed accumulators
     void *d_t4 = nullptr, *d_w2 = nullptr;   // OT4 scratch fields, [max_shots][field] each
+    // TTI state: parameter fields [6][field], field pairs [2][max_shots][3][field] (forward u,v / adjoint p,r),
+    // scratch [5][max_shots][field] (wA, wB, gzA, gzB, sum)
+    void *tti_par = nullptr, *tti_fwd = nullptr, *tti_adj = nullptr, *tti_tmp = nullptr;
+    bool tti_fwd_valid = false, tti_adj_valid = false;
     void *d_dm = nullptr;                    // [field] haloed model perturbation of the Born operator
     void *d_dense = nullptr;                 // dense staging, max(max_shots*ngrid, ...) elements
     size_t dense_elems = 0;
@@ -225,6 +229,28 @@ int launch_pack(const Plan &p, const T *dense, T *haloed, long shot_stride, int 
 template <typename T>
 int launch_l2_misfit(const Plan &p, const T *syn, const T *obs, T *res, long n_per_shot, int nshots,
                      double *partial, double *fval);
+
+// ---- TTI propagators (kernels_tti.hip) ----------------------------------------------------------
+template <typename T>
+struct TtiParams {
+    const T *et, *dl, *ct, *st, *cp, *sp;  // haloed: 1+2eps, sqrt(1+2delta), cos/sin(theta), cos/sin(phi)
+    T a[kMaxR / 2 + 1];                    // centred first-derivative weights a_1..a_p
+    T ih[3];                               // 1/h per canonical dimension
+    int p;                                 // space_order / 4
+};
+template <typename T>
+struct TtiLevels {
+    const T *ucur, *uold, *vcur, *vold;    // shot 0
+    T *uout, *vout;
+    long shot_stride;
+};
+// fill a haloed parameter field: halo_value everywhere, then f(dense) on the grid points
+// (mode 1: 1+2x, 2: sqrt(1+2x), 3: cos, 4: sin); dense == null leaves the constant
+template <typename T>
+int launch_tti_param(const Plan &p, const StepConsts<T> &k, const T *dense, T *haloed, int mode, T halo_value);
+template <typename T>
+int launch_tti_step(const Plan &p, const StepConsts<T> &k, const TtiParams<T> &q, int fwd, const TtiLevels<T> &lv,
+                    T *wA, T *wB, T *gzA, T *gzB, T *sum, int nshots, int &launches);
 
 // ---- tiled 2-D fast path (kernels_tiled2d.hip) -------------------------------------------------
 // LDS row pitch (floats) of a staged tile: a multiple of 64 so that the rows a wave touches with

@@ -13,7 +13,7 @@ EXPORTED_SYMBOLS = (
     "mifwi_version", "mifwi_last_error", "mifwi_plan_create", "mifwi_plan_destroy", "mifwi_set_stream",
     "mifwi_synchronize", "mifwi_set_model", "mifwi_set_geometry", "mifwi_forward", "mifwi_adjoint",
     "mifwi_gradient", "mifwi_l2_misfit_gradient", "mifwi_read_wavefield", "mifwi_write_wavefield",
-    "mifwi_get_stats", "mifwi_born",
+    "mifwi_get_stats", "mifwi_born", "mifwi_tti_set_model", "mifwi_tti_forward", "mifwi_tti_adjoint",
 )
 
 
@@ -80,6 +80,9 @@ def load_library():
     lib.mifwi_forward.argtypes = [vp, i32, vp, i32, vp, i32]
     lib.mifwi_adjoint.argtypes = [vp, i32, vp, vp]
     lib.mifwi_born.argtypes = [vp, i32, vp, i32, vp, vp]
+    lib.mifwi_tti_set_model.argtypes = [vp, vp, vp, vp, vp]
+    lib.mifwi_tti_forward.argtypes = [vp, i32, vp, i32, vp]
+    lib.mifwi_tti_adjoint.argtypes = [vp, i32, vp, vp]
     lib.mifwi_gradient.argtypes = [vp, i32, vp, vp, i32, vp]
     lib.mifwi_l2_misfit_gradient.argtypes = [vp, i32, vp, i32, vp, vp, vp, vp, vp, vp]
     lib.mifwi_read_wavefield.argtypes = [vp, i32, i32, i32, i32, vp]
@@ -215,6 +218,33 @@ class Plan(object):
         pr, rec = self._out(rec_out, (nshots, self.nt, self.nrec))
         self._check(self._lib.mifwi_born(self._h, nshots, pw, int(bool(wavelet_per_shot)), pd, pr))
         return rec
+
+    # -- TTI ('centered' kernel) -----------------------------------------------------------------
+    def tti_set_model(self, epsilon, delta, theta, phi=None):
+        """Thomsen parameters and angles over the padded grid (phi only in 3-D, may be None)."""
+        ptrs, keep = [], []
+        for a in (epsilon, delta, theta, phi):
+            pa, ka = self._in(a)
+            if ka is not None:
+                n = ka.numel() if _is_torch(ka) else ka.size
+                assert n == self.ngrid, "TTI parameters must cover the padded grid"
+            ptrs.append(pa)
+            keep.append(ka)
+        self._check(self._lib.mifwi_tti_set_model(self._h, *ptrs))
+
+    def tti_forward(self, wavelet, nshots=None, rec_out=None, wavelet_per_shot=False):
+        nshots = nshots or self.nshots
+        pw, kw = self._in(wavelet)
+        pr, rec = self._out(rec_out, (nshots, self.nt, self.nrec))
+        self._check(self._lib.mifwi_tti_forward(self._h, nshots, pw, int(bool(wavelet_per_shot)), pr))
+        return rec
+
+    def tti_adjoint(self, rec_in, nshots=None, srca_out=None):
+        nshots = nshots or self.nshots
+        pi, ki = self._in(rec_in)
+        po, srca = self._out(srca_out, (nshots, self.nt, self.nsrc))
+        self._check(self._lib.mifwi_tti_adjoint(self._h, nshots, pi, po))
+        return srca
 
     def adjoint(self, rec_in, nshots=None, srca_out=None):
         nshots = nshots or self.nshots

@@ -1,10 +1,10 @@
 """
-Host-side physical model: padded grid, edge-padded velocity, sponge profile, CFL time step.
+Host-side physical model: padded grid, edge-padded parameters, sponge profile, CFL time step.
 
 Mirrors the interface of the reference's seismic/model.py (`SeismicModel`, alias `Model`) for the
-isotropic acoustic case with numpy arrays in place of Devito functions; every attribute the FWI
+acoustic case (isotropic or TTI) with numpy arrays in place of Devito functions; every attribute the FWI
 drivers and `AcousticWaveSolver` touch is present with the same meaning (reference file:line
-given per member).  Elastic / visco / TTI parameters are outside this package's scope and raise.
+given per member).  Elastic / visco parameters are outside this package's scope and raise.
 """
 import numpy as np
 
@@ -150,17 +150,21 @@ class SeismicModel(GenericModel):
     `dt=` (keyword) is the local extension of the reference: a user time step that must not exceed
     the CFL value (model.py:277-278,366-369).
     """
-    _known_parameters = ['vp', 'damp']
-    _unsupported = ('vs', 'b', 'epsilon', 'delta', 'theta', 'phi', 'qp', 'qs', 'lam', 'mu')
+    _known_parameters = ['vp', 'damp', 'epsilon', 'delta', 'theta', 'phi']
+    _unsupported = ('vs', 'b', 'qp', 'qs', 'lam', 'mu')
 
     def __init__(self, origin, spacing, shape, space_order, vp, nbl=20, fs=False, dtype=np.float32,
                  subdomains=(), bcs="mask", grid=None, **kwargs):
         for k in self._unsupported:
             if kwargs.get(k) is not None and not (k == 'b' and np.all(np.asarray(kwargs[k]) == 1)):
-                raise NotImplementedError("parameter %r: only isotropic acoustic models are supported" % k)
+                raise NotImplementedError("parameter %r: only acoustic (isotropic or TTI) models are supported" % k)
         super(SeismicModel, self).__init__(origin, spacing, shape, space_order, nbl, dtype, subdomains,
                                            grid=grid, bcs=bcs, fs=fs)
         self.vp = self._gen_phys_param(vp, 'vp', space_order)
+        # Thomsen parameters and tilt / azimuth angles of a TTI medium (model.py:285-315)
+        for name in ('epsilon', 'delta', 'theta', 'phi'):
+            if kwargs.get(name) is not None:
+                setattr(self, name, self._gen_phys_param(kwargs.get(name), name, space_order))
         self._dt = kwargs.get('dt')
         self._dt_scale = 1
 
@@ -189,6 +193,13 @@ class SeismicModel(GenericModel):
         return np.max(self.vp.data)
 
     @property
+    def _thomsen_scale(self):
+        """sqrt(1 + 2 max(epsilon)) for anisotropic media (model.py:324-329)."""
+        if 'epsilon' in self._physical_parameters:
+            return np.sqrt(1 + 2 * np.max(self.epsilon.data))
+        return 1
+
+    @property
     def dt_scale(self):
         return self._dt_scale
 
@@ -205,7 +216,7 @@ class SeismicModel(GenericModel):
     @property
     def critical_dt(self):
         """CFL time step rounded through '%.3e' in the grid dtype (model.py:355-370)."""
-        dt = self._cfl_coeff * np.min(self.spacing) / self._max_vp
+        dt = self._cfl_coeff * np.min(self.spacing) / (self._thomsen_scale * self._max_vp)
         dt = self.dtype("%.3e" % (self.dt_scale * dt))
         if self._dt:
             if self._dt > dt:

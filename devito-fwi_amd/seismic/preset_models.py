@@ -49,4 +49,31 @@ def demo_model(preset, **kwargs):
         return SeismicModel(space_order=space_order, vp=v, origin=origin, shape=shape, dtype=dtype,
                             spacing=spacing, nbl=nbl, bcs="damp", fs=fs, **kwargs)
 
-    raise NotImplementedError("preset %r: only the isotropic acoustic presets are available" % preset)
+    if name == 'constant-tti':
+        # preset_models.py:93-107 of the reference
+        v = np.full(shape, 1.5, dtype=dtype)
+        phi = .35 * np.ones(shape, dtype=dtype) if len(shape) > 2 else None
+        return SeismicModel(space_order=space_order, vp=v, origin=origin, shape=shape, dtype=dtype,
+                            spacing=spacing, nbl=nbl, epsilon=.3 * np.ones(shape, dtype=dtype),
+                            delta=.2 * np.ones(shape, dtype=dtype), theta=.7 * np.ones(shape, dtype=dtype),
+                            phi=phi, bcs="damp", **kwargs)
+
+    if name in ('layers-tti', 'layers-tti-noazimuth'):
+        # preset_models.py:197-229 of the reference: Thomsen parameters and angles scale with vp - 1.5
+        vp_top = kwargs.pop('vp_top', 1.5)
+        vp_bottom = kwargs.pop('vp_bottom', 3.5)
+        smooth = kwargs.pop('smooth', False)
+        v = np.full(shape, vp_top, dtype=dtype)
+        levels = np.linspace(vp_top, vp_bottom, nlayers)
+        thickness = int(shape[-1] / nlayers)
+        for i in range(1, nlayers):
+            v[..., i * thickness:] = levels[i]
+        azimuth = len(shape) > 2 and name != 'layers-tti-noazimuth'
+        model = SeismicModel(space_order=space_order, vp=v, origin=origin, shape=shape, dtype=dtype,
+                             spacing=spacing, nbl=nbl, epsilon=.3 * (v - 1.5), delta=.2 * (v - 1.5),
+                             theta=.5 * (v - 1.5), phi=.25 * (v - 1.5) if azimuth else None, bcs="damp", **kwargs)
+        if smooth:
+            model.smooth(('epsilon', 'delta', 'theta', 'phi') if azimuth else ('epsilon', 'delta', 'theta'))
+        return model
+
+    raise NotImplementedError("preset %r: only the acoustic (isotropic and TTI) presets are available" % preset)

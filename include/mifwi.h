@@ -173,6 +173,21 @@ int mifwi_l2_misfit_gradient(mifwi_plan *plan, int32_t nshots, const void *wavel
                              int32_t wavelet_per_shot, const void *obs, double *fval, void *grad,
                              void *illum, void *residual_out, void *syn_out);
 
+/* ---- TTI media, 'centered' kernel (seismic/tti/operators.py:198-313,430-519 and
+ * seismic/tti/wavesolver.py:80-215 of the reference) -------------------------------------------
+ * mifwi_tti_set_model replaces the epsilon / delta / theta / phi operator arguments
+ * (wavesolver.py:153-159): arrays over the padded grid like vp (mifwi_set_model still supplies vp and
+ * damp); phi may be NULL (2-D, or no azimuth).  space_order must be divisible by 4; 2-D or 3-D.
+ * mifwi_tti_forward replaces op_fwd('centered').apply (wavesolver.py:160-166): the wavelet drives
+ * both fields, rec_out (nshots, nt, nrec) samples u + v.  mifwi_tti_adjoint replaces op_adj().apply
+ * (wavesolver.py:208-215): rec_in (nshots, nt, nrec) -> srca_out (nshots, nt, nsrc).  The last three
+ * levels of (u, v) and (p, r) are readable through mifwi_read_wavefield which = 3, 4 and 5, 6. */
+int mifwi_tti_set_model(mifwi_plan *plan, const void *epsilon, const void *delta, const void *theta,
+                        const void *phi);
+int mifwi_tti_forward(mifwi_plan *plan, int32_t nshots, const void *wavelet, int32_t wavelet_per_shot,
+                      void *rec_out);
+int mifwi_tti_adjoint(mifwi_plan *plan, int32_t nshots, const void *rec_in, void *srca_out);
+
 /* Access to wavefield time levels of one shot, `u.data[first:first+count]` in the reference
  * (TimeFunction(save=nt), seismic/acoustic/wavesolver.py:104-106).  which = 0: saved forward
  * field (level index = time).  which = 1: the three rotating buffers of the last non-saving

@@ -257,6 +257,51 @@ class Problem(object):
         return rec
 
 
+class TTIProblem(Problem):
+    """Tilted transversely isotropic medium, 'centered' kernel (seismic/tti/operators.py,
+    seismic/tti/wavesolver.py:80-215; parameters as seismic/model.py:285-315).  epsilon, delta, theta
+    (and phi in 3-D) over the physical grid; they are edge-padded into the absorbing layer like vp."""
+
+    def __init__(self, vp, spacing, nbl, space_order, epsilon, delta, theta, phi=None, **kw):
+        super(TTIProblem, self).__init__(vp, spacing, nbl, space_order, **kw)
+        assert not self.fs and not self.ot4 and space_order % 4 == 0
+
+        def padded(a):
+            return None if a is None else np.ascontiguousarray(pad_vp(np.asarray(a, dtype=self.dtype), self.nbl))
+        self.epsilon, self.delta, self.theta, self.phi = padded(epsilon), padded(delta), padded(theta), padded(phi)
+
+    @property
+    def critical_dt(self):
+        """model.py:324-329,355-370: the CFL velocity is scaled by sqrt(1 + 2 max(epsilon))."""
+        scale = np.sqrt(1 + 2 * float(self.epsilon.max()))
+        return critical_dt(scale * float(self.vp.max()), self.spacing, self.model_space_order, self.dtype,
+                           self.user_dt)
+
+    def _run(self, name, src_coords, src, rec_coords, rec, dt):
+        fn = getattr(lib(), name + _sfx(self.dtype))
+        sc, rc_ = self._coords(src_coords), self._coords(rec_coords)
+        nt = src.shape[0]
+        r = fn(self.ndim, _ia(self.shape_pad), _da(self.spacing), _da(self.origin_pad), self.space_order, nt,
+               ctypes.c_double(dt), _p(self.vp), _p(self.damp), _p(self.epsilon), _p(self.delta), _p(self.theta),
+               _p(self.phi), sc.shape[0], _p(sc), _p(src), rc_.shape[0], _p(rc_), _p(rec))
+        assert r == 0, r
+
+    def forward(self, src_coords, wavelet, rec_coords, dt=None):
+        dt = float(self.critical_dt if dt is None else dt)
+        nsrc = self._coords(src_coords).shape[0]
+        w = np.ascontiguousarray(np.asarray(wavelet, dtype=self.dtype).reshape(-1, nsrc))
+        rec = np.zeros((w.shape[0], self._coords(rec_coords).shape[0]), dtype=self.dtype)
+        self._run("oracle_tti_forward_", src_coords, w, rec_coords, rec, dt)
+        return rec
+
+    def adjoint(self, src_coords, rec_coords, rec, dt=None):
+        dt = float(self.critical_dt if dt is None else dt)
+        rec = np.ascontiguousarray(rec, dtype=self.dtype)
+        srca = np.zeros((rec.shape[0], self._coords(src_coords).shape[0]), dtype=self.dtype)
+        self._run("oracle_tti_adjoint_", src_coords, srca, rec_coords, rec, dt)
+        return srca
+
+
 # ----------------------------------------------------------------------------------------------
 # FWI glue (fwi.py of the reference)
 # ----------------------------------------------------------------------------------------------

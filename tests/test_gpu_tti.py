@@ -1,0 +1,92 @@
+"""GPU parity of the TTI propagators (mifwi_tti_set_model / mifwi_tti_forward / mifwi_tti_adjoint;
+reference seismic/tti/operators.py:198-313,430-519) against the CPU oracle, the adjoint-pair
+identity on the GPU, and the reference's stability test through the drop-in solver.
+Tolerances: rel-L2 <= 2e-5 on records (float32; two coupled fields and nested first derivatives
+accumulate a little more rounding than the acoustic kernels), 1e-11 in float64.  The reference pins
+no TTI numbers, so parity here is against the restatement only."""
+import numpy as np
+import pytest
+
+from helpers import rel_l2
+from test_oracle_tti import tti_case
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def mifwi():
+    import mifwi as m
+    return m
+
+
+def _plan(mifwi, prob, nt, dt, nsrc, nrec, src, rec):
+    plan = mifwi.Plan(prob.shape_pad, prob.spacing, prob.origin_pad, prob.space_order, nt, dt, nsrc, nrec,
+                      max_shots=1, dtype=prob.dtype)
+    plan.set_model(prob.vp, prob.damp)
+    plan.tti_set_model(prob.epsilon, prob.delta, prob.theta, prob.phi)
+    plan.set_geometry(src.reshape(1, nsrc, -1), rec)
+    return plan
+
+
+@pytest.mark.parametrize("dtype,tol", [(np.float32, 2e-5), (np.float64, 1e-11)])
+@pytest.mark.parametrize("shape,so", [((41, 37), 8), ((45, 33), 4), ((19, 17, 21), 8), ((21, 18, 70), 4)])
+def test_tti_forward_adjoint_parity(mifwi, shape, so, dtype, tol):
+    prob, vp, src, rec, rng = tti_case(shape, so=so, dtype=dtype)
+    dt = float(prob.critical_dt)
+    nt = 100 if len(shape) == 2 else 45
+    w = orc.ricker(0.03, dt * np.arange(nt)).reshape(nt, 1).astype(dtype)
+    src, rec = src.astype(dtype), rec.astype(dtype)
+    plan = _plan(mifwi, prob, nt, dt, 1, rec.shape[0], src, rec)
+    d = plan.tti_forward(w)[0]
+    ref = prob.forward(src, w, rec, dt=dt)
+    assert np.abs(ref).max() > 0
+    assert rel_l2(d, ref) <= tol
+    a = plan.tti_adjoint(ref[None])[0]
+    assert rel_l2(a, prob.adjoint(src, rec, ref, dt=dt)) <= 5 * tol
+    u, v = plan.read_wavefield(3), plan.read_wavefield(4)
+    assert u.shape == (3,) + prob.shape_pad and np.abs(u).max() > 0 and np.abs(v).max() > 0
+    plan.close()
+
+
+def test_tti_adjoint_pair_on_gpu(mifwi):
+    prob, vp, src, rec, rng = tti_case((37, 41), so=8, dtype=np.float64)
+    dt, nt = float(prob.critical_dt), 120
+    plan = _plan(mifwi, prob, nt, dt, 1, rec.shape[0], src, rec)
+    s = rng.standard_normal((nt, 1))
+    r = rng.standard_normal((1, nt, rec.shape[0]))
+    fs = plan.tti_forward(s)
+    ftr = plan.tti_adjoint(r)
+    lhs, rhs = float(np.sum(fs * r)), float(np.sum(s * ftr[0]))
+    assert abs(lhs - rhs) <= 1e-11 * max(abs(lhs), abs(rhs))
+    plan.close()
+
+
+def test_tti_requires_model_and_order(mifwi):
+    plan = mifwi.Plan((30, 30), (10., 10.), (0., 0.), 4, 10, 1.0, 1, 1)
+    plan.set_model(np.full((30, 30), 2.0, np.float32), np.zeros((30, 30), np.float32))
+    plan.set_geometry(np.array([[[100., 100.]]], np.float32), np.array([[150., 150.]], np.float32))
+    with pytest.raises(mifwi.MifwiError):
+        plan.tti_forward(np.zeros((10, 1), np.float32))
+    plan.close()
+    plan = mifwi.Plan((30, 30), (10., 10.), (0., 0.), 6, 10, 1.0, 1, 1)
+    z = np.zeros((30, 30), np.float32)
+    with pytest.raises(mifwi.MifwiError):
+        plan.tti_set_model(z, z, z)
+    plan.close()
+
+
+@pytest.mark.parametrize("ndim", [2, 3])
+def test_tti_stability_through_solver(ndim):
+    """tti_example.py:42-49 through AnisotropicWaveSolver: finite records after tn = 16000."""
+    from seismic import demo_model, setup_geometry
+    from seismic.tti import AnisotropicWaveSolver
+    model = demo_model('layers-tti', shape=(11,) * ndim, spacing=(20.,) * ndim, space_order=4, nbl=0)
+    geometry = setup_geometry(model, 16000.0)
+    solver = AnisotropicWaveSolver(model, geometry, space_order=4)
+    rec, u, v, summary = solver.forward()
+    assert np.isfinite(np.linalg.norm(rec.data.astype(np.float64))) and np.abs(rec.data).max() > 0
+    srca, p, r, _ = solver.adjoint(rec)
+    assert np.isfinite(np.linalg.norm(srca.data.astype(np.float64)))
+    with pytest.raises(NotImplementedError):
+        solver.jacobian_adjoint(rec, u, v)
