@@ -45,6 +45,11 @@ __device__ inline void st4_out(float *p, float4 v)
     *reinterpret_cast<float4 *>(p) = v;
 #endif
 }
+__device__ inline void st4_stream(float *p, float4 v)
+{
+    vfloat4_2d t = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(t, reinterpret_cast<vfloat4_2d *>(p));
+}
 __device__ inline float4 ld4_saved(const float *p)
 {
 #ifdef MIFWI_2D_NT_LOAD
@@ -200,6 +205,17 @@ __global__ __launch_bounds__(256) void step2d_kernel(Step2DArgs a)
         } else {
             for (int i = 0; i < 4; ++i)
                 if (z + i < a.n2) a.out[ps + i] = res[i];
+        }
+        if (a.copy) {
+            // the saved forward level is a write-only stream here: the time loop itself runs on the
+            // three rotating levels, which stay cache resident
+            float *cp = a.copy + (long)shot * a.copy_shot_stride + p;
+            if (full) {
+                st4_stream(cp, make_float4(res[0], res[1], res[2], res[3]));
+            } else {
+                for (int i = 0; i < 4; ++i)
+                    if (z + i < a.n2) cp[i] = res[i];
+            }
         }
         if (a.fs && z <= R) {
             // free surface: row -zi of the z halo mirrors row zi with the opposite sign, so that the

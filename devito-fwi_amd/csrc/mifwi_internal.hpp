@@ -286,6 +286,9 @@ struct Step2DArgs {
     float *vals_out;
     int time, nt;
     int fs;   // free surface: keep the antisymmetric mirror of rows z = 1..R in the z halo of `out`
+    // second, streamed copy of `out` (the saved forward level), or null
+    float *copy;
+    long copy_shot_stride;
 };
 int launch_step2d(const Plan &p, const Step2DArgs &a, hipStream_t stream);
 
