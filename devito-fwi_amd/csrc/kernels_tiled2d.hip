@@ -2,7 +2,7 @@
 //
 // One launch advances every shot of the batch by one time step and also does that step's sparse
 // work, so a time loop is exactly one kernel per step:
-//   * tile blocks: each 256-thread block owns a TX x TZ tile of one shot.  The tile of the field
+//   * tile blocks: each block of TX*TZ/4 threads owns a TX x TZ tile of one shot.  The tile of the field
 //     read through the stencil (plus a halo of R rows / round_up(R,4) columns) is staged in LDS with
 //     16-byte loads; every thread then produces 4 consecutive z points from ds_read_b128 reads (the
 //     z line once, 2R row neighbours), reads old/m/eta with one aligned 16-byte load each and
@@ -61,25 +61,26 @@ __device__ inline float4 ld4_saved(const float *p)
 }
 
 template <int R, int TX, int TZ, bool GRAD>
-__global__ __launch_bounds__(256) void step2d_kernel(Step2DArgs a)
+__global__ __launch_bounds__(TX *TZ / 4) void step2d_kernel(Step2DArgs a)
 {
     constexpr int RZ = (R + 3) / 4 * 4;          // z halo in LDS, multiple of 4
     constexpr int ROWF4 = (TZ + 2 * RZ) / 4;     // float4 per staged row
     constexpr int P = tile2d_lds_pitch(TZ, R);   // LDS row pitch in floats
     constexpr int TQ = TZ / 4;                   // threads per tile row
-    constexpr int NSTAGE = ((TX + 2 * R) * ROWF4 + 255) / 256;  // staged float4 per thread
-    static_assert(TQ * TX == 256, "one float4 per thread");
+    constexpr int NT = TX * TQ;                   // threads per block: one float4 of the tile each
+    constexpr int NSTAGE = ((TX + 2 * R) * ROWF4 + NT - 1) / NT;  // staged float4 per thread
+    static_assert(NT % 64 == 0 && NT <= 1024, "whole wavefronts");
     __shared__ __attribute__((aligned(16))) float lds[(TX + 2 * R) * P];
     __shared__ __attribute__((aligned(16))) float acc[TX * TZ];   // injected terms of this tile
 
     const int tid = threadIdx.x;
-    const int nitp_blocks = a.pt_idx ? ((a.itp_npoint + 255) / 256) * a.nshots : 0;
+    const int nitp_blocks = a.pt_idx ? ((a.itp_npoint + NT - 1) / NT) * a.nshots : 0;
     int bid = blockIdx.x;
 
     if (bid < nitp_blocks) {
         // ---- interpolation role (first in the grid: two dependent loads, start them early) -----
         const int shot = a.shot0 + bid % a.nshots;
-        const int pnt = (bid / a.nshots) * 256 + tid;
+        const int pnt = (bid / a.nshots) * NT + tid;
         if (pnt >= a.itp_npoint) return;
         const int tab = a.itp_per_shot ? shot : 0;
         const int4 idx = *reinterpret_cast<const int4 *>(a.pt_idx + ((long)tab * a.itp_npoint + pnt) * 4);
@@ -108,7 +109,7 @@ __global__ __launch_bounds__(256) void step2d_kernel(Step2DArgs a)
     float4 stage[NSTAGE];
 #pragma unroll
     for (int i = 0; i < NSTAGE; ++i) {
-        const int c = tid + i * 256;
+        const int c = tid + i * NT;
         const int row = c / ROWF4, q = c - row * ROWF4;
         const int gx = x0 - R + row;
         stage[i] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -137,7 +138,7 @@ __global__ __launch_bounds__(256) void step2d_kernel(Step2DArgs a)
         __syncthreads();
         const float *vals = a.vals_inj + ((long)shot * a.nt + a.time) * a.inj_npoint;
         const long tbase = ((long)inj_tab * (a.ntx * a.ntz) + tile) * a.inj_cap;
-        for (int j = tid; j < ninj; j += 256) {
+        for (int j = tid; j < ninj; j += NT) {
             const int local = a.slot_local[tbase + j];
             const int32_t *ep = a.slot_ep + (tbase + j) * a.inj_maxe;
             const float *ew = a.slot_ew + (tbase + j) * a.inj_maxe;
@@ -152,7 +153,7 @@ __global__ __launch_bounds__(256) void step2d_kernel(Step2DArgs a)
     // ---- stage the tile of `cur` (with halo) in LDS --------------------------------------------
 #pragma unroll
     for (int i = 0; i < NSTAGE; ++i) {
-        const int c = tid + i * 256;
+        const int c = tid + i * NT;
         const int row = c / ROWF4, q = c - row * ROWF4;
         if (c < (TX + 2 * R) * ROWF4) *reinterpret_cast<float4 *>(&lds[row * P + 4 * q]) = stage[i];
     }
@@ -255,9 +256,9 @@ template <int R, int TX, int TZ>
 static int launch_rt(const Plan &p, const Step2DArgs &a, int nblocks, hipStream_t stream)
 {
     if (a.um)
-        hipLaunchKernelGGL((step2d_kernel<R, TX, TZ, true>), dim3(nblocks), dim3(256), 0, stream, a);
+        hipLaunchKernelGGL((step2d_kernel<R, TX, TZ, true>), dim3(nblocks), dim3(TX * TZ / 4), 0, stream, a);
     else
-        hipLaunchKernelGGL((step2d_kernel<R, TX, TZ, false>), dim3(nblocks), dim3(256), 0, stream, a);
+        hipLaunchKernelGGL((step2d_kernel<R, TX, TZ, false>), dim3(nblocks), dim3(TX * TZ / 4), 0, stream, a);
     MIFWI_HIP(hipGetLastError());
     return MIFWI_OK;
 }
@@ -266,13 +267,15 @@ template <int R>
 static int launch_r(const Plan &p, const Step2DArgs &a, int nblocks, hipStream_t stream)
 {
     if (p.tile_tz == 64) return launch_rt<R, 16, 64>(p, a, nblocks, stream);
+    if (p.tile_tx == 48) return launch_rt<R, 48, 32>(p, a, nblocks, stream);
+    if (p.tile_tx == 24) return launch_rt<R, 24, 32>(p, a, nblocks, stream);
     return launch_rt<R, 32, 32>(p, a, nblocks, stream);
 }
 
 int launch_step2d(const Plan &p, const Step2DArgs &a, hipStream_t stream)
 {
-    const int nblocks = a.ntx * a.ntz * a.nshots + (a.pt_idx ? ((a.itp_npoint + 255) / 256) * a.nshots : 0);
-    if (a.slot_count && 4 * 256 < p.tile_tx * p.tile_tz) return MIFWI_EINVAL;
+    const int nthreads = p.tile_tx * p.tile_tz / 4;
+    const int nblocks = a.ntx * a.ntz * a.nshots + (a.pt_idx ? ((a.itp_npoint + nthreads - 1) / nthreads) * a.nshots : 0);
     switch (p.L.R) {
         case 1: return launch_r<1>(p, a, nblocks, stream);
         case 2: return launch_r<2>(p, a, nblocks, stream);

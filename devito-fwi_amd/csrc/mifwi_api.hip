@@ -443,6 +443,7 @@ static int create(const mifwi_config *cfg, mifwi_plan **out)
         p->kind = 1;
         if (waste(16, 64) <= waste(32, 32)) p->tile_tx = 16, p->tile_tz = 64;
         else p->tile_tx = 32, p->tile_tz = 32;
+        if (const char *env = getenv("MIFWI_2D_TX")) p->tile_tx = atoi(env), p->tile_tz = 32;  // tuning experiments
         p->ntx = (n1 + p->tile_tx - 1) / p->tile_tx;
         p->ntz = (n2 + p->tile_tz - 1) / p->tile_tz;
     }

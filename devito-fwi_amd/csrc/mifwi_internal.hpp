@@ -253,9 +253,17 @@ int launch_tti_step(const Plan &p, const StepConsts<T> &k, const TtiParams<T> &q
                     T *wA, T *wB, T *gzA, T *gzB, T *sum, int nshots, int &launches);
 
 // ---- tiled 2-D fast path (kernels_tiled2d.hip) -------------------------------------------------
-// LDS row pitch (floats) of a staged tile: a multiple of 64 so that the rows a wave touches with
-// one ds_read_b128 fall on disjoint bank groups.
-constexpr int tile2d_lds_pitch(int TZ, int R) { return ((TZ + 2 * ((R + 3) / 4 * 4)) + 63) / 64 * 64; }
+// LDS row pitch (floats) of a staged tile.  ds_read_b128 serves a wave in four groups of 16 lanes
+// over 64 banks; a group spans two tile rows when a row is 8 lanes (TZ = 32) and one row plus parts
+// of others when it is 16 lanes (TZ = 64).  Rows must therefore start half a bank row apart for
+// TZ = 32 (pitch = 32 mod 64) and a whole bank row apart for TZ = 64 (pitch = 0 mod 64); with a
+// pitch of 0 mod 64 the 32-wide tile had every read 2-way conflicted.
+constexpr int tile2d_lds_pitch(int TZ, int R)
+{
+    const int need = TZ + 2 * ((R + 3) / 4 * 4);
+    if (TZ == 32) return (need + 31) / 64 * 64 + 32;
+    return (need + 63) / 64 * 64;
+}
 
 struct Step2DArgs {
     const float *cur, *old;
