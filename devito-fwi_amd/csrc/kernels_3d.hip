@@ -246,20 +246,9 @@ __global__ __launch_bounds__(TY *TZ / V, (GRAD ? MIFWI_3D_GRAD_WAVES : 3) * (TY 
             if (inj_beg < inj_end) {
                 for (int j = tid; j < TY * TZ; j += NT) acc[j] = 0.f;
                 __syncthreads();
-                const float *vals = a.vals_inj + ((long)shot * a.nt + a.time) * a.inj_npoint;
-                const int32_t *uptr = a.uc_ptr + (long)inj_tab * (a.inj_kmax + 1);
-                const int32_t *ep = a.e_point + (long)inj_tab * a.inj_kmax;
-                const float *ew = a.e_w + (long)inj_tab * a.inj_kmax;
-                for (int j = inj_beg + tid; j < inj_end; j += NT) {
-                    const long cj = (long)inj_tab * a.inj_kmax + j;
-                    const int local = a.cell_local[cj];
-                    const int u = a.cell_uc[cj];
-                    float sum = 0.f;
-                    for (int e = uptr[u]; e < uptr[u + 1]; ++e) sum += ew[e] * vals[ep[e]];
-                    const int ly = local / TZ, lz = local - ly * TZ;
-                    const float mc = a.m[a.off0 + (long)x * a.s0 + (long)(y0 + ly) * a.s1 + (z0 + lz)];
-                    acc[local] = sum * a.dt2 / mc;
-                }
+                const float *w = a.winj + ((long)shot * a.nt + a.time) * a.winj_stride;
+                for (int j = inj_beg + tid; j < inj_end; j += NT)
+                    acc[a.cell_local[(long)inj_tab * a.inj_kmax + j]] = w[j];
             }
         }
         __syncthreads();

@@ -290,6 +290,44 @@ __global__ __launch_bounds__(256) void sparse_kernel(SparseDev<T> d)
     }
 }
 
+// Injected terms of all time steps (see Plan::d_winj).  blockIdx = (cell chunk, time chunk, shot).
+constexpr int kPrepTimes = 16;
+__global__ __launch_bounds__(256) void inject_prepare_kernel(const int32_t *g_u, const int32_t *uc_cell,
+                                                             const int32_t *uc_ptr, const int32_t *uc_count,
+                                                             const int32_t *e_point, const float *e_w, int kmax,
+                                                             int npoint, int per_shot, const float *vals, const float *m,
+                                                             int nt, float dt2, float *winj)
+{
+    const int shot = blockIdx.z;
+    const int tab = per_shot ? shot : 0;
+    const int g = blockIdx.x * 256 + threadIdx.x;
+    if (g >= uc_count[tab]) return;
+    const int u = g_u[(long)tab * kmax + g];
+    const int e0 = uc_ptr[(long)tab * (kmax + 1) + u], e1 = uc_ptr[(long)tab * (kmax + 1) + u + 1];
+    const float scale = dt2 / m[uc_cell[(long)tab * kmax + u]];
+    const int32_t *ep = e_point + (long)tab * kmax;
+    const float *ew = e_w + (long)tab * kmax;
+    const int t0 = blockIdx.y * kPrepTimes, t1 = min(nt, t0 + kPrepTimes);
+    for (int time = t0; time < t1; ++time) {
+        const float *v = vals + ((long)shot * nt + time) * npoint;
+        float sum = 0.f;
+        for (int e = e0; e < e1; ++e) sum += ew[e] * v[ep[e]];
+        winj[((long)shot * nt + time) * kmax + g] = sum * scale;
+    }
+}
+
+int launch_inject_prepare(const Plan &p, const SparseSet &S, const int32_t *g_u, const float *vals, int nshots,
+                          float dt2, float *winj)
+{
+    if (S.npoint <= 0 || S.max_count <= 0) return MIFWI_OK;
+    dim3 grid((S.max_count + 255) / 256, (p.cfg.nt + kPrepTimes - 1) / kPrepTimes, nshots);
+    hipLaunchKernelGGL(inject_prepare_kernel, grid, dim3(256), 0, p.stream, g_u, S.uc_cell, S.uc_ptr, S.uc_count,
+                       S.e_point, (const float *)S.e_w, S.kmax, S.npoint, S.per_shot, vals, (const float *)p.m, p.cfg.nt,
+                       dt2, winj);
+    MIFWI_HIP(hipGetLastError());
+    return MIFWI_OK;
+}
+
 template <typename T>
 int launch_sparse(const Plan &p, const SparsePtrs<T> &sp, int nshots)
 {

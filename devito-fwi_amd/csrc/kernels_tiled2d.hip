@@ -61,7 +61,11 @@ __device__ inline float4 ld4_saved(const float *p)
 }
 
 template <int R, int TX, int TZ, bool GRAD>
-__global__ __launch_bounds__(TX *TZ / 4) void step2d_kernel(Step2DArgs a)
+// Register budget of the gradient variant: 128 VGPRs, i.e. four blocks per CU (unconstrained it takes
+// 136 and three).  A batch of 8 shots is ~3.1 tiles per CU, so with three resident blocks the last
+// tiles of a launch wait for a free slot: 7.6 -> 6.6 us per step.  The plain variant fits anyway and
+// schedules better without the bound.
+__global__ __launch_bounds__(TX *TZ / 4, GRAD ? 4 : 1) void step2d_kernel(Step2DArgs a)
 {
     constexpr int RZ = (R + 3) / 4 * 4;          // z halo in LDS, multiple of 4
     constexpr int ROWF4 = (TZ + 2 * RZ) / 4;     // float4 per staged row
@@ -132,22 +136,14 @@ __global__ __launch_bounds__(TX *TZ / 4) void step2d_kernel(Step2DArgs a)
         }
     }
 
-    // ---- injected terms of the cells this tile owns (rare: block-uniform branch) ---------------
+    // ---- injected terms of the cells this tile owns (rare: block-uniform branch): the terms were
+    // formed before the time loop, so both loads are independent of everything else in flight
     if (ninj > 0) {
         *reinterpret_cast<float4 *>(&acc[4 * tid]) = make_float4(0.f, 0.f, 0.f, 0.f);
         __syncthreads();
-        const float *vals = a.vals_inj + ((long)shot * a.nt + a.time) * a.inj_npoint;
-        const long tbase = ((long)inj_tab * (a.ntx * a.ntz) + tile) * a.inj_cap;
-        for (int j = tid; j < ninj; j += NT) {
-            const int local = a.slot_local[tbase + j];
-            const int32_t *ep = a.slot_ep + (tbase + j) * a.inj_maxe;
-            const float *ew = a.slot_ew + (tbase + j) * a.inj_maxe;
-            float sum = 0.f;
-            for (int e = 0; e < a.inj_maxe; ++e) sum += ew[e] * vals[ep[e]];
-            const int lx = local / TZ, lz = local - lx * TZ;
-            const float mc = a.m[a.off0 + (long)(x0 + lx) * a.s1 + (z0 + lz)];
-            acc[local] = sum * a.dt2 / mc;
-        }
+        const long tslot = (long)inj_tab * (a.ntx * a.ntz) + tile;
+        const float *w = a.winj + ((long)shot * a.nt + a.time) * a.winj_stride + a.slot_base[tslot];
+        for (int j = tid; j < ninj; j += NT) acc[a.slot_local[tslot * a.inj_cap + j]] = w[j];
     }
 
     // ---- stage the tile of `cur` (with halo) in LDS --------------------------------------------

@@ -126,6 +126,8 @@ static void free_sparse(SparseSet &s)
     dev_free(s.slot_local);
     dev_free(s.slot_ep);
     dev_free(s.slot_ew);
+    dev_free(s.slot_base);
+    dev_free(s.g_u);
     dev_free(s.cell_ptr);
     dev_free(s.cell_local);
     dev_free(s.cell_uc);
@@ -160,6 +162,8 @@ static void destroy(Plan *p)
     dev_free(p->d_grad);
     dev_free(p->d_illum);
     dev_free(p->d_dm);
+    dev_free(p->d_winj[0]);
+    dev_free(p->d_winj[1]);
     dev_free(p->tti_par);
     dev_free(p->tti_fwd);
     dev_free(p->tti_adj);
@@ -234,6 +238,7 @@ static int build_sparse(Plan &p, SparseSet &S, const T *coords /* [tables][npoin
     // per table and tile: (tile-local cell, [(point, weight)...]) lists, flattened after the loop
     std::vector<std::vector<std::vector<std::pair<int32_t, std::vector<std::pair<int32_t, T>>>>>> tiles(
         ntiles ? tables : 0);
+    std::vector<std::vector<std::vector<int32_t>>> tile_u(ntiles ? tables : 0);  // unique-cell index per (table, tile, slot)
     struct Entry {
         int32_t cell;
         int32_t point;
@@ -327,6 +332,7 @@ static int build_sparse(Plan &p, SparseSet &S, const T *coords /* [tables][npoin
         if (ntiles) {
             auto &tt = tiles[t];
             tt.resize(ntiles);
+            tile_u[t].resize(ntiles);
             for (int u = 0; u < nu; ++u) {
                 const long rel = (long)cellp[u] - L.off0;
                 const int i1 = (int)(rel / L.s1), i2 = (int)(rel % L.s1);
@@ -336,13 +342,16 @@ static int build_sparse(Plan &p, SparseSet &S, const T *coords /* [tables][npoin
                 for (int e = ptrp[u]; e < ptrp[u + 1]; ++e) es.push_back({ent[e].point, ent[e].w});
                 S.maxe = std::max(S.maxe, (int)es.size());
                 tt[tile].push_back({local, std::move(es)});
+                tile_u[t][tile].push_back(u);
                 S.cap = std::max(S.cap, (int)tt[tile].size());
             }
         }
     }
-    std::vector<int32_t> slot_count, slot_local, slot_ep;
+    std::vector<int32_t> slot_count, slot_local, slot_ep, slot_base, g_u;
     std::vector<T> slot_ew;
     if (ntiles) {
+        slot_base.assign((size_t)tables * ntiles, 0);
+        g_u.assign((size_t)tables * S.kmax, 0);
         S.cap = std::max(S.cap, 1);
         S.maxe = std::max(S.maxe, 1);
         slot_count.assign((size_t)tables * ntiles, 0);
@@ -353,9 +362,13 @@ static int build_sparse(Plan &p, SparseSet &S, const T *coords /* [tables][npoin
             for (int tl = 0; tl < ntiles; ++tl) {
                 const auto &cells = tiles[t][tl];
                 slot_count[(size_t)t * ntiles + tl] = (int32_t)cells.size();
+                slot_base[(size_t)t * ntiles + tl] = tl ? slot_base[(size_t)t * ntiles + tl - 1] +
+                                                              slot_count[(size_t)t * ntiles + tl - 1]
+                                                        : 0;
                 for (size_t c = 0; c < cells.size(); ++c) {
                     const size_t sl = ((size_t)t * ntiles + tl) * S.cap + c;
                     slot_local[sl] = cells[c].first;
+                    g_u[(size_t)t * S.kmax + slot_base[(size_t)t * ntiles + tl] + c] = tile_u[t][tl][c];
                     for (size_t e = 0; e < cells[c].second.size(); ++e) {
                         slot_ep[sl * S.maxe + e] = cells[c].second[e].first;
                         slot_ew[sl * S.maxe + e] = cells[c].second[e].second;
@@ -386,6 +399,8 @@ static int build_sparse(Plan &p, SparseSet &S, const T *coords /* [tables][npoin
         if ((rc = up((void **)&S.slot_local, slot_local.data(), slot_local.size() * 4))) return rc;
         if ((rc = up((void **)&S.slot_ep, slot_ep.data(), slot_ep.size() * 4))) return rc;
         if ((rc = up(&S.slot_ew, slot_ew.data(), slot_ew.size() * sizeof(T)))) return rc;
+        if ((rc = up((void **)&S.slot_base, slot_base.data(), slot_base.size() * 4))) return rc;
+        if ((rc = up((void **)&S.g_u, g_u.data(), g_u.size() * 4))) return rc;
     }
     // the host vectors die at return: make sure the uploads have been consumed
     MIFWI_HIP(hipStreamSynchronize(p.stream));
@@ -608,18 +623,36 @@ static Step2DArgs base2d(const Plan &p, int nshots)
     a.fs = (p.cfg.flags & MIFWI_FLAG_FREE_SURFACE) ? 1 : 0;
     return a;
 }
-static void set_inject(Step2DArgs &a, const SparseSet &S, const void *vals)
+// Form the injected terms of every time step of the coming loop (tiled kernels only).
+template <typename T>
+static int prepare_injection(Plan &p, const SparseSet &S, const void *vals, int nshots)
+{
+    if (p.kind == 0 || S.npoint <= 0 || S.max_count <= 0) return MIFWI_OK;
+    const size_t need = (size_t)p.cfg.max_shots * p.cfg.nt * S.kmax;
+    const int w = (&S == &p.rec) ? 1 : 0;
+    int rc;
+    if (need > p.winj_elems[w]) {
+        clear_graphs(p);   // captured loops hold the old address
+        dev_free(p.d_winj[w]);
+        p.d_winj[w] = nullptr, p.winj_elems[w] = 0;
+        if ((rc = dev_alloc(p, &p.d_winj[w], need * sizeof(float), false))) return rc;
+        p.winj_elems[w] = need;
+    }
+    const float dt = (float)p.cfg.dt;
+    return launch_inject_prepare(p, S, p.kind == 1 ? S.g_u : S.cell_uc, (const float *)vals, nshots, dt * dt,
+                                 (float *)p.d_winj[w]);
+}
+
+static void set_inject(Step2DArgs &a, const SparseSet &S, const Plan &p)
 {
     if (S.npoint <= 0 || S.max_count <= 0) return;
     a.slot_count = S.slot_count;
     a.slot_local = S.slot_local;
-    a.slot_ep = S.slot_ep;
-    a.slot_ew = (const float *)S.slot_ew;
+    a.slot_base = S.slot_base;
     a.inj_cap = S.cap;
-    a.inj_maxe = S.maxe;
-    a.inj_npoint = S.npoint;
     a.inj_per_shot = S.per_shot;
-    a.vals_inj = (const float *)vals;
+    a.winj = (const float *)p.d_winj[&S == &p.rec ? 1 : 0];
+    a.winj_stride = S.kmax;
 }
 static void set_interp(Step2DArgs &a, const SparseSet &S, void *vals_out)
 {
@@ -695,19 +728,15 @@ static Step3DArgs base3d(const Plan &p, int nshots, bool grad)
     a.fs = (p.cfg.flags & MIFWI_FLAG_FREE_SURFACE) ? 1 : 0;
     return a;
 }
-static void set_inject3(Step3DArgs &a, const SparseSet &S, const void *vals)
+static void set_inject3(Step3DArgs &a, const SparseSet &S, const Plan &p)
 {
     if (S.npoint <= 0 || S.max_count <= 0) return;
     a.cell_ptr = S.cell_ptr;
     a.cell_local = S.cell_local;
-    a.cell_uc = S.cell_uc;
-    a.uc_ptr = S.uc_ptr;
-    a.e_point = S.e_point;
-    a.e_w = (const float *)S.e_w;
     a.inj_kmax = S.kmax;
-    a.inj_npoint = S.npoint;
     a.inj_per_shot = S.per_shot;
-    a.vals_inj = (const float *)vals;
+    a.winj = (const float *)p.d_winj[&S == &p.rec ? 1 : 0];
+    a.winj_stride = S.kmax;
 }
 static void set_interp3(Step3DArgs &a, const SparseSet &S, void *vals_out)
 {
@@ -750,7 +779,7 @@ static int forward_step(Plan &p, const LoopCtx<T> &c, const T *cur, const T *old
     if (p.kind == 1) {
         Step2DArgs a = c.a2;
         a.shot_stride = shot_stride;
-        if (inject) set_inject(a, p.src, p.d_wavelet);
+        if (inject) set_inject(a, p.src, p);
         if (interp) set_interp(a, p.rec, p.d_rec);
         a.cur = (const float *)cur, a.old = (const float *)old, a.out = (float *)out, a.time = time;
         a.copy = (float *)copy, a.copy_shot_stride = copy_stride;
@@ -761,7 +790,7 @@ static int forward_step(Plan &p, const LoopCtx<T> &c, const T *cur, const T *old
     if (p.kind == 2) {
         Step3DArgs a = c.a3;
         a.shot_stride = shot_stride;
-        if (inject) set_inject3(a, p.src, p.d_wavelet);
+        if (inject) set_inject3(a, p.src, p);
         if (interp) set_interp3(a, p.rec, p.d_rec);
         a.cur = (const float *)cur, a.old = (const float *)old, a.out = (float *)out, a.time = time;
         if ((rc = launch_step3d(p, a, p.stream))) return rc;
@@ -810,7 +839,7 @@ static int backward_step(Plan &p, const LoopCtx<T> &c, const T *cur, const T *ol
     if (p.kind == 1) {
         Step2DArgs a = c.a2;
         a.shot_stride = shot_stride;
-        set_inject(a, p.rec, p.d_res);
+        set_inject(a, p.rec, p);
         if (!with_grad) set_interp(a, p.src, p.d_srca);
         a.cur = (const float *)cur, a.old = (const float *)old, a.out = (float *)out, a.time = time;
         if (with_grad) {
@@ -828,7 +857,7 @@ static int backward_step(Plan &p, const LoopCtx<T> &c, const T *cur, const T *ol
     if (p.kind == 2) {
         Step3DArgs a = c.a3;
         a.shot_stride = shot_stride;
-        set_inject3(a, p.rec, p.d_res);
+        set_inject3(a, p.rec, p);
         if (!with_grad) set_interp3(a, p.src, p.d_srca);
         a.cur = (const float *)cur, a.old = (const float *)old, a.out = (float *)out, a.time = time;
         if (with_grad) {
@@ -996,6 +1025,7 @@ static int run_forward(Plan &p, int nshots, int save)
     }
     if (save) p.saved_valid = false;
     MIFWI_HIP(hipMemsetAsync(p.d_rec, 0, (size_t)nshots * nt * p.cfg.nrec * sizeof(T), p.stream));
+    if ((rc = prepare_injection<T>(p, p.src, p.d_wavelet, nshots))) return rc;
     const LoopCtx<T> ctx = make_ctx<T>(p, nshots, false);
     const long sv_lstride = (long)p.cfg.max_shots * L.field;
     const bool in_saved = full_save && !copy_save;
@@ -1057,6 +1087,8 @@ static int run_backward(Plan &p, int nshots, bool with_grad, bool with_illum)
     } else {
         MIFWI_HIP(hipMemsetAsync(p.d_srca, 0, (size_t)nshots * nt * p.cfg.nsrc * sizeof(T), p.stream));
     }
+    if ((rc = prepare_injection<T>(p, p.rec, p.d_res, nshots))) return rc;
+    if (with_grad && p.ck_K > 0 && (rc = prepare_injection<T>(p, p.src, p.d_wavelet, nshots))) return rc;  // recomputation
     const LoopCtx<T> ctx = make_ctx<T>(p, nshots, with_grad);
     const LoopCtx<T> fctx = make_ctx<T>(p, nshots, false);
     auto lvl = [&](int t) { return base + (long)((t + 3) % 3) * L.field; };
@@ -1152,6 +1184,7 @@ static int born(Plan &p, int nshots, const void *wavelet, int per_shot, const vo
     MIFWI_HIP(hipMemsetAsync(bU, 0, (size_t)nshots * stride * sizeof(T), p.stream));
     MIFWI_HIP(hipMemsetAsync(p.d_rec, 0, (size_t)nshots * nt * p.cfg.nrec * sizeof(T), p.stream));
     p.rot_u_valid = p.rot_v_valid = false;
+    if ((rc = prepare_injection<T>(p, p.src, p.d_wavelet, nshots))) return rc;
     const LoopCtx<T> ctx = make_ctx<T>(p, nshots, false);
     const int ghost = (ctx.k.fs && p.kind != 0) ? 1 : 0;
     auto enqueue = [&](int &launches) -> int {

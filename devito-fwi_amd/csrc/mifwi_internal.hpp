@@ -81,6 +81,8 @@ struct SparseSet {
     int32_t *slot_local = nullptr; // [tables][ntiles][cap] tile-local cell index, -1 = empty
     int32_t *slot_ep = nullptr;    // [tables][ntiles][cap][maxe] point index (0 when padding)
     void *slot_ew = nullptr;       // [tables][ntiles][cap][maxe] weight (0 when padding)
+    int32_t *slot_base = nullptr;  // [tables][ntiles] first position of the tile's cells in tile-major order
+    int32_t *g_u = nullptr;        // [tables][kmax] unique-cell index (into uc_*) of tile-major position g
     // Injection view of the 2.5-D kernel: owned cells ordered by ((y,z) tile, x plane)
     int32_t *cell_ptr = nullptr;   // [tables][ntiles][n0+1] ranges into cell_local / cell_uc
     int32_t *cell_local = nullptr; // [tables][kmax] tile-local (y,z) index of the cell
@@ -123,6 +125,11 @@ struct Plan {
     // scratch [5][max_shots][field] (wA, wB, gzA, gzB, sum)
     void *tti_par = nullptr, *tti_fwd = nullptr, *tti_adj = nullptr, *tti_tmp = nullptr;
     bool tti_fwd_valid = false, tti_adj_valid = false;
+    // Injected terms of every time step, formed once before a time loop of the tiled kernels:
+    // winj[shot][time][g] = (sum_e w_e vals[shot][time][point_e]) * dt^2 / m[cell], g in the order the
+    // kernels walk the cells (tile-major slots in 2-D, cell_local order in 3-D)
+    void *d_winj[2] = {nullptr, nullptr};   // [0]: terms of the sources, [1]: of the receivers
+    size_t winj_elems[2] = {0, 0};
     void *d_dm = nullptr;                    // [field] haloed model perturbation of the Born operator
     void *d_dense = nullptr;                 // dense staging, max(max_shots*ngrid, ...) elements
     size_t dense_elems = 0;
@@ -216,6 +223,10 @@ template <typename T>
 int launch_born_source(const Plan &p, const StepConsts<T> &k, const T *u_new, const T *u_cur, const T *u_old,
                        long shot_stride, const T *dm, T *U_out, long U_shot_stride, int nshots, int ghost);
 
+// winj[shot][time][g] for g < uc_count[table]: see Plan::d_winj.  g_u maps g to the unique cell.
+int launch_inject_prepare(const Plan &p, const SparseSet &S, const int32_t *g_u, const float *vals, int nshots,
+                          float dt2, float *winj);
+
 template <typename T>
 int launch_prep_model(const Plan &p, const T *vp_dense, const T *damp_dense, T *m, T *eta);
 
@@ -282,11 +293,12 @@ struct Step2DArgs {
     float *grad, *illum;
     long g_shot_stride;
     int first;
-    // injection (slot_count == nullptr: none)
-    const int32_t *slot_count, *slot_local, *slot_ep;
-    const float *slot_ew;
-    int inj_cap, inj_maxe, inj_npoint, inj_per_shot;
-    const float *vals_inj;
+    // injection (slot_count == nullptr: none): per tile the cells it owns, and their precomputed
+    // terms winj[shot][time][slot_base[tile] + j]
+    const int32_t *slot_count, *slot_local, *slot_base;
+    int inj_cap, inj_per_shot;
+    const float *winj;
+    long winj_stride;   // cells per (shot, time)
     // interpolation of `cur` (pt_idx == nullptr: none)
     const int32_t *pt_idx;
     const float *pt_w;
@@ -318,11 +330,12 @@ struct Step3DArgs {
     float *grad, *illum;
     long g_shot_stride;
     int first;
-    // injection (cell_ptr == nullptr: none)
-    const int32_t *cell_ptr, *cell_local, *cell_uc, *uc_ptr, *e_point;
-    const float *e_w;
-    int inj_kmax, inj_npoint, inj_per_shot;
-    const float *vals_inj;
+    // injection (cell_ptr == nullptr: none): cells ordered by (tile, plane) and their precomputed
+    // terms winj[shot][time][position]
+    const int32_t *cell_ptr, *cell_local;
+    int inj_kmax, inj_per_shot;
+    const float *winj;
+    long winj_stride;
     // interpolation of `cur` (pt_idx == nullptr: none)
     const int32_t *pt_idx;
     const float *pt_w;

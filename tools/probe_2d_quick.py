@@ -19,10 +19,17 @@ for save in (False, True):
         t.append(st["fwd_ms"] * 1e3 / st["fwd_launches"])
     out.append(min(t))
 rec = plan.forward(case.wavelet, save=True)
-g = []
+g, g2, ad = [], [], []
 for _ in range(4):
     plan.gradient(rec, want_illum=True)
     st = plan.stats()
     g.append(st["bwd_ms"] * 1e3 / st["bwd_launches"])
-print("%s so=%2d shots=%2d  fwd nosave %.2f us  save %.2f us  grad %.2f us" %
-      (os.path.basename(os.environ.get("MIFWI_LIB", "libmifwi.so")), so, ns, out[0], out[1], min(g)), flush=True)
+    plan.gradient(rec, want_illum=False)
+    st = plan.stats()
+    g2.append(st["bwd_ms"] * 1e3 / st["bwd_launches"])
+    plan.adjoint(rec)
+    st = plan.stats()
+    ad.append(st["bwd_ms"] * 1e3 / st["bwd_launches"])
+print("%s so=%2d shots=%2d  fwd nosave %.2f us  save %.2f us  grad %.2f us  grad-noillum %.2f us  adjoint %.2f us" %
+      (os.path.basename(os.environ.get("MIFWI_LIB", "libmifwi.so")), so, ns, out[0], out[1], min(g), min(g2), min(ad)),
+      flush=True)
