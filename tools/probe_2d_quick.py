@@ -7,7 +7,7 @@ import mifwi
 from helpers import Case
 so = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 ns = int(sys.argv[2]) if len(sys.argv) > 2 else 8
-case = Case((340, 140), (25., 25.), nbl=40, space_order=so, nt=600, nshots=ns, nrec=340, seed=1)
+case = Case((340, 140), (25., 25.), nbl=40, space_order=so, nt=int(os.environ.get("PROBE_NT", "600")), nshots=ns, nrec=340, seed=1)
 plan = case.plan(mifwi)
 out = []
 for save in (False, True):
