@@ -2,7 +2,7 @@
 """
 Benchmark of the acoustic FWI hot path on MI355X.
 
-Metric (BASELINE.json): Gpoints/s (forward + adjoint/gradient) on Marmousi-II, 8 shots per GPU.
+Metric: Gpoints/s (forward + adjoint/gradient) on Marmousi-II, 8 shots per GPU.
 One "step" = one gradient evaluation of the L2 objective for this rank's 8 shots:
 forward modelling with the wavefield saved on the device, residual against the observed data,
 backward propagation with zero-lag cross-correlation, per-shot source/receiver muting and the

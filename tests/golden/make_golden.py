@@ -5,7 +5,7 @@ has been pinned against the reference's known-answer tests (tests/test_oracle_ka
 
     python tests/golden/make_golden.py
 
-Cases (inputs follow BASELINE.json's configs; Marmousi rasters are the reference's
+Cases (inputs follow the benchmark configurations; Marmousi rasters are the reference's
 model_data/SMARMN and model_data/SMARM2 files kept under tests/golden/model_data):
   c1_constant      demo_model('constant-isotropic') 101^2, space_order 4, setup_geometry(tn=1000), 1 shot
   c2_marmousi      SMARMN 300x106, space_order 8, dt 2.95, tn 4000, shot 3 of 8 (marmousi_fwi.py:62-117)

@@ -1,5 +1,5 @@
 """
-GPU parity against the committed golden vectors at BASELINE.json's full 2-D sizes (Marmousi,
+GPU parity against the committed golden vectors at the full 2-D benchmark sizes (Marmousi,
 space order 8; Marmousi-II, space order 16) plus the constant-model and small 3-D cases.
 Tolerances as in test_gpu_parity_abi.py: rel-L2 1e-5 on records, 1e-4 on gradient/illumination,
 objective to 1e-5 relative.

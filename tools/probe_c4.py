@@ -1,4 +1,4 @@
-"""GPU probe: BASELINE config C4 on one GPU -- synthetic 3-D 512^3 (+nbl 40), 1 shot, nt=500:
+"""GPU probe: the large 3-D benchmark configuration on one GPU -- synthetic 3-D 512^3 (+nbl 40), 1 shot, nt=500:
 forward with (checkpointed) wavefield + L2 gradient through the C ABI."""
 import os, sys, time
 import numpy as np
