@@ -45,6 +45,31 @@ __device__ inline void st4_out(float *p, float4 v)
     *reinterpret_cast<float4 *>(p) = v;
 #endif
 }
+// 16-byte accesses addressed as a block-uniform (SGPR) base pointer plus a 32-bit per-lane byte offset:
+// the cheapest global addressing mode, no 64-bit vector address arithmetic.  One field level stays
+// below 4 GB (checked when the plan is created).
+__device__ inline float4 ld4_at(const char *base, unsigned off)
+{
+    return *reinterpret_cast<const float4 *>(base + off);
+}
+__device__ inline float4 ld4_stream_at(const char *base, unsigned off)
+{
+#ifdef MIFWI_2D_NT_LOAD
+    const vfloat4_2d v = __builtin_nontemporal_load(reinterpret_cast<const vfloat4_2d *>(base + off));
+    return make_float4(v.x, v.y, v.z, v.w);
+#else
+    return *reinterpret_cast<const float4 *>(base + off);
+#endif
+}
+__device__ inline void st4_at(char *base, unsigned off, float4 v)
+{
+    *reinterpret_cast<float4 *>(base + off) = v;
+}
+__device__ inline void st4_stream_at(char *base, unsigned off, float4 v)
+{
+    vfloat4_2d t = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(t, reinterpret_cast<vfloat4_2d *>(base + off));
+}
 __device__ inline void st4_stream(float *p, float4 v)
 {
     vfloat4_2d t = {v.x, v.y, v.z, v.w};
@@ -100,12 +125,15 @@ __global__ __launch_bounds__(TX *TZ / 4, GRAD ? 4 : 1) void step2d_kernel(Step2D
     const int tile = bid / a.nshots;
     const int tile_x = tile / a.ntz, tile_z = tile - tile_x * a.ntz;
     const int x0 = tile_x * TX, z0 = tile_z * TZ;
-    const float *cur = a.cur + (long)shot * a.shot_stride + a.off0;
     const int tx = tid / TQ, tq = tid - tx * TQ;
     const int x = x0 + tx, z = z0 + 4 * tq;
     const bool live = (x < a.n1) && (z < a.n2);
     const long p = a.off0 + (long)x * a.s1 + z;
     const long ps = (long)shot * a.shot_stride + p;
+    const unsigned pb = ((unsigned)a.off0 + (unsigned)x * (unsigned)a.s1 + (unsigned)z) * 4u;   // byte offset of (x, z)
+    const char *curb = reinterpret_cast<const char *>(a.cur + (long)shot * a.shot_stride);
+    const char *oldb = reinterpret_cast<const char *>(a.old + (long)shot * a.shot_stride);
+    char *outb = reinterpret_cast<char *>(a.out + (long)shot * a.shot_stride);
 
     // ---- issue every global load up front: they share one memory round trip -------------------
     const int inj_tab = a.inj_per_shot ? shot : 0;
@@ -118,21 +146,20 @@ __global__ __launch_bounds__(TX *TZ / 4, GRAD ? 4 : 1) void step2d_kernel(Step2D
         const int gx = x0 - R + row;
         stage[i] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (c < (TX + 2 * R) * ROWF4 && gx < a.n1 + R)
-            stage[i] = *reinterpret_cast<const float4 *>(cur + (long)gx * a.s1 + (z0 - RZ + 4 * q));
+            stage[i] = ld4_at(curb, (unsigned)((int)a.off0 + gx * (int)a.s1 + (z0 - RZ + 4 * q)) * 4u);
     }
     float4 m4 = make_float4(1.f, 1.f, 1.f, 1.f), e4 = make_float4(0.f, 0.f, 0.f, 0.f), o4 = e4;
     float4 u04 = e4, up4 = e4, gv = e4, iv = e4;
-    const long qs = (long)shot * a.u_shot_stride + p;
     const long gs = (long)shot * a.g_shot_stride + p;
     if (live) {
-        m4 = *reinterpret_cast<const float4 *>(a.m + p);
-        e4 = *reinterpret_cast<const float4 *>(a.eta + p);
-        o4 = *reinterpret_cast<const float4 *>(a.old + ps);
+        m4 = ld4_at(reinterpret_cast<const char *>(a.m), pb);
+        e4 = ld4_at(reinterpret_cast<const char *>(a.eta), pb);
+        o4 = ld4_at(oldb, pb);
         if (GRAD) {
-            u04 = ld4_saved(a.uc + qs);
-            if (a.first && a.illum) up4 = *reinterpret_cast<const float4 *>(a.up + qs);
-            gv = *reinterpret_cast<const float4 *>(a.grad + gs);
-            if (a.illum) iv = *reinterpret_cast<const float4 *>(a.illum + gs);
+            u04 = ld4_stream_at(reinterpret_cast<const char *>(a.uc + (long)shot * a.u_shot_stride), pb);
+            if (a.first && a.illum) up4 = ld4_at(reinterpret_cast<const char *>(a.up + (long)shot * a.u_shot_stride), pb);
+            gv = ld4_at(reinterpret_cast<const char *>(a.grad + (long)shot * a.g_shot_stride), pb);
+            if (a.illum) iv = ld4_at(reinterpret_cast<const char *>(a.illum + (long)shot * a.g_shot_stride), pb);
         }
     }
 
@@ -198,7 +225,7 @@ __global__ __launch_bounds__(TX *TZ / 4, GRAD ? 4 : 1) void step2d_kernel(Step2D
         }
         const bool full = (z + 3 < a.n2);
         if (full) {
-            st4_out(a.out + ps, make_float4(res[0], res[1], res[2], res[3]));
+            st4_at(outb, pb, make_float4(res[0], res[1], res[2], res[3]));
         } else {
             for (int i = 0; i < 4; ++i)
                 if (z + i < a.n2) a.out[ps + i] = res[i];
@@ -208,7 +235,8 @@ __global__ __launch_bounds__(TX *TZ / 4, GRAD ? 4 : 1) void step2d_kernel(Step2D
             // three rotating levels, which stay cache resident
             float *cp = a.copy + (long)shot * a.copy_shot_stride + p;
             if (full) {
-                st4_stream(cp, make_float4(res[0], res[1], res[2], res[3]));
+                st4_stream_at(reinterpret_cast<char *>(a.copy + (long)shot * a.copy_shot_stride), pb,
+                              make_float4(res[0], res[1], res[2], res[3]));
             } else {
                 for (int i = 0; i < 4; ++i)
                     if (z + i < a.n2) cp[i] = res[i];
@@ -235,8 +263,10 @@ __global__ __launch_bounds__(TX *TZ / 4, GRAD ? 4 : 1) void step2d_kernel(Step2D
                 il[i] += u0[i] * u0[i] + up[i] * up[i];
             }
             if (full) {
-                *reinterpret_cast<float4 *>(a.grad + gs) = make_float4(g[0], g[1], g[2], g[3]);
-                if (a.illum) *reinterpret_cast<float4 *>(a.illum + gs) = make_float4(il[0], il[1], il[2], il[3]);
+                st4_at(reinterpret_cast<char *>(a.grad + (long)shot * a.g_shot_stride), pb, make_float4(g[0], g[1], g[2], g[3]));
+                if (a.illum)
+                    st4_at(reinterpret_cast<char *>(a.illum + (long)shot * a.g_shot_stride), pb,
+                           make_float4(il[0], il[1], il[2], il[3]));
             } else {
                 for (int i = 0; i < 4; ++i)
                     if (z + i < a.n2) {

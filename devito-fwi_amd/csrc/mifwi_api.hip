@@ -476,6 +476,8 @@ static int create(const mifwi_config *cfg, mifwi_plan **out)
         p->bpc_grad = step3d_blocks_per_cu(p->L.R, true);
         if (const char *env = getenv("MIFWI_3D_NCHUNK")) p->nchunk_env = std::max(1, atoi(env));  // tuning experiments
     }
+    // the tiled kernels address a field level with 32-bit byte offsets
+    if (p->kind != 0 && (unsigned long long)p->L.field * 4ull >= (1ull << 32)) p->kind = 0;
     auto bail = [&](int code) {
         destroy(p);
         return code;
