@@ -257,6 +257,8 @@ def main():
         packed, st = step()
         fwd_stats.append((st["fwd_ms"], st["fwd_launches"]))
         grad_stats.append((st["bwd_ms"], st["bwd_launches"]))
+        if os.environ.get("BENCH_VERBOSE"):
+            print("step: fwd %.3f ms  bwd %.3f ms" % (st["fwd_ms"], st["bwd_ms"]), file=sys.stderr)
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:

@@ -28,4 +28,14 @@ for name, srcs, recs in (("bench geometry", src_all, rec),
         st = plan.stats()
         g.append(st["bwd_ms"] * 1e3 / st["bwd_launches"])
     print("%-28s fwd save %.2f us  grad %.2f us" % (name, min(t), min(g)), flush=True)
+    if os.environ.get("PROBE_SUSTAIN"):
+        import time
+        for k in range(12):
+            t0 = time.perf_counter()
+            plan.forward(wav, save=True, want_rec=False)
+            f = plan.stats()["fwd_ms"]
+            plan.gradient(r, want_illum=True)
+            b = plan.stats()["bwd_ms"]
+            print("   pass %2d: fwd %.3f ms  bwd %.3f ms  wall %.2f ms" % (k, f, b, (time.perf_counter() - t0) * 1e3), flush=True)
+        break
     plan.close()
