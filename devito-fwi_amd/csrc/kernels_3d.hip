@@ -94,9 +94,11 @@ __device__ inline void lds_stv(float *p, const float (&d)[V])
 #ifndef MIFWI_3D_GRAD_WAVES
 #define MIFWI_3D_GRAD_WAVES 2
 #endif
-template <int R, int TY, int TZ, int V, bool GRAD, bool ISO>
-__global__ __launch_bounds__(TY *TZ / V, (GRAD ? MIFWI_3D_GRAD_WAVES : 3) * (TY * TZ / V) / 256) void step3d_kernel(Step3DArgs a)
+// MODE 0: plain propagation, 1: gradient, 2: scattered field of Born modelling.
+template <int R, int TY, int TZ, int V, int MODE, bool ISO>
+__global__ __launch_bounds__(TY *TZ / V, (MODE != 0 ? MIFWI_3D_GRAD_WAVES : 3) * (TY * TZ / V) / 256) void step3d_kernel(Step3DArgs a)
 {
+    constexpr bool GRAD = (MODE == 1), BORN = (MODE == 2);
     constexpr int NT = TY * TZ / V;                     // threads per block
     constexpr int RZ = (R + 3) / 4 * 4;
     constexpr int RZ4 = RZ / 4;
@@ -259,6 +261,18 @@ __global__ __launch_bounds__(TY *TZ / V, (GRAD ? MIFWI_3D_GRAD_WAVES : 3) * (TY 
             for (int i = 0; i < NHT; ++i)
                 if (h_ok[i]) ldv<4>(cur + (long)(x + 1) * sb, h_glb[i], hv[i]);
         }
+        float bn[V], bc[V], bo[V], bd[V];
+        if (BORN) {
+#pragma unroll
+            for (int i = 0; i < V; ++i) bn[i] = bc[i] = bo[i] = bd[i] = 0.f;
+            if (live) {
+                const long bs = (long)shot * a.b_shot_stride * 4 + (long)x * sb;
+                ldv_stream<V>(reinterpret_cast<const char *>(a.b_un) + bs, col, bn);
+                ldv_stream<V>(reinterpret_cast<const char *>(a.b_uc) + bs, col, bc);
+                ldv_stream<V>(reinterpret_cast<const char *>(a.b_uo) + bs, col, bo);
+                ldv_stream<V>(reinterpret_cast<const char *>(a.b_dm) + (long)x * sb, col, bd);
+            }
+        }
         float u0[V], up[V], g[V], il[V];
         char *gradb = nullptr, *illumb = nullptr;
         if (GRAD) {
@@ -324,6 +338,13 @@ __global__ __launch_bounds__(TY *TZ / V, (GRAD ? MIFWI_3D_GRAD_WAVES : 3) * (TY 
             for (int i = 0; i < V; ++i) {
                 const float ed = ee[i] * a.dt;
                 res[i] = fast_div3(a.dt2 * lap[i] + 2.0f * mm[i] * uc[i] - mm[i] * oo[i] + ed * uc[i], mm[i] + ed);
+            }
+            if (BORN) {
+#pragma unroll
+                for (int i = 0; i < V; ++i) {
+                    const float utt = (bn[i] - 2.0f * bc[i] + bo[i]) * a.inv_dt2;
+                    res[i] += fast_div3(a.dt2 * (-bd[i] * utt), mm[i] + ee[i] * a.dt);
+                }
             }
             if (inj_beg < inj_end) {
 #pragma unroll
@@ -403,9 +424,13 @@ static int launch_r3v(const Plan &p, const Step3DArgs &a, hipStream_t stream)
     const int nitp = a.pt_idx ? (((a.itp_npoint + NT - 1) / NT) * a.nshots + 7) / 8 * 8 : 0;
     const int nblocks = (a.nwork + 7) / 8 * 8 + nitp;
     if (a.um)
-        hipLaunchKernelGGL((step3d_kernel<R, 16, 64, V, true, ISO>), dim3(nblocks), dim3(NT), 0, stream, a);
+        hipLaunchKernelGGL((step3d_kernel<R, 16, 64, V, 1, ISO>), dim3(nblocks), dim3(NT), 0, stream, a);
+    else if (a.b_un)   // always four points per thread
+        hipLaunchKernelGGL((step3d_kernel<R, 16, 64, 4, 2, ISO>), dim3((a.nwork + 7) / 8 * 8 +
+                               (a.pt_idx ? (((a.itp_npoint + 255) / 256) * a.nshots + 7) / 8 * 8 : 0)),
+                           dim3(256), 0, stream, a);
     else
-        hipLaunchKernelGGL((step3d_kernel<R, 16, 64, V, false, ISO>), dim3(nblocks), dim3(NT), 0, stream, a);
+        hipLaunchKernelGGL((step3d_kernel<R, 16, 64, V, 0, ISO>), dim3(nblocks), dim3(NT), 0, stream, a);
     MIFWI_HIP(hipGetLastError());
     return MIFWI_OK;
 }
@@ -414,8 +439,8 @@ template <int R>
 static int occupancy_r3(bool grad)
 {
     int nb = 0;
-    hipError_t e = grad ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, step3d_kernel<R, 16, 64, 4, true, true>, 256, 0)
-                        : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, step3d_kernel<R, 16, 64, 4, false, true>, 256, 0);
+    hipError_t e = grad ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, step3d_kernel<R, 16, 64, 4, 1, true>, 256, 0)
+                        : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, step3d_kernel<R, 16, 64, 4, 0, true>, 256, 0);
     if (e != hipSuccess) {
         (void)hipGetLastError();
         return 2;

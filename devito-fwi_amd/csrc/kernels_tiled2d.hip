@@ -85,13 +85,15 @@ __device__ inline float4 ld4_saved(const float *p)
 #endif
 }
 
-template <int R, int TX, int TZ, bool GRAD>
+// MODE 0: plain propagation, 1: gradient, 2: scattered field of Born modelling.
+template <int R, int TX, int TZ, int MODE>
 // Register budget of the gradient variant: 128 VGPRs, i.e. four blocks per CU (unconstrained it takes
 // 136 and three).  A batch of 8 shots is ~3.1 tiles per CU, so with three resident blocks the last
 // tiles of a launch wait for a free slot: 7.6 -> 6.6 us per step.  The plain variant fits anyway and
 // schedules better without the bound.
-__global__ __launch_bounds__(TX *TZ / 4, GRAD ? 4 : 1) void step2d_kernel(Step2DArgs a)
+__global__ __launch_bounds__(TX *TZ / 4, MODE == 1 ? 4 : 1) void step2d_kernel(Step2DArgs a)
 {
+    constexpr bool GRAD = (MODE == 1), BORN = (MODE == 2);
     constexpr int RZ = (R + 3) / 4 * 4;          // z halo in LDS, multiple of 4
     constexpr int ROWF4 = (TZ + 2 * RZ) / 4;     // float4 per staged row
     constexpr int P = tile2d_lds_pitch(TZ, R);   // LDS row pitch in floats
@@ -150,6 +152,7 @@ __global__ __launch_bounds__(TX *TZ / 4, GRAD ? 4 : 1) void step2d_kernel(Step2D
     }
     float4 m4 = make_float4(1.f, 1.f, 1.f, 1.f), e4 = make_float4(0.f, 0.f, 0.f, 0.f), o4 = e4;
     float4 u04 = e4, up4 = e4, gv = e4, iv = e4;
+    float4 bn4 = e4, bc4 = e4, bo4 = e4, bd4 = e4;
     const long gs = (long)shot * a.g_shot_stride + p;
     if (live) {
         m4 = ld4_at(reinterpret_cast<const char *>(a.m), pb);
@@ -160,6 +163,12 @@ __global__ __launch_bounds__(TX *TZ / 4, GRAD ? 4 : 1) void step2d_kernel(Step2D
             if (a.first && a.illum) up4 = ld4_at(reinterpret_cast<const char *>(a.up + (long)shot * a.u_shot_stride), pb);
             gv = ld4_at(reinterpret_cast<const char *>(a.grad + (long)shot * a.g_shot_stride), pb);
             if (a.illum) iv = ld4_at(reinterpret_cast<const char *>(a.illum + (long)shot * a.g_shot_stride), pb);
+        }
+        if (BORN) {
+            bn4 = ld4_at(reinterpret_cast<const char *>(a.b_un + (long)shot * a.b_shot_stride), pb);
+            bc4 = ld4_at(reinterpret_cast<const char *>(a.b_uc + (long)shot * a.b_shot_stride), pb);
+            bo4 = ld4_at(reinterpret_cast<const char *>(a.b_uo + (long)shot * a.b_shot_stride), pb);
+            bd4 = ld4_at(reinterpret_cast<const char *>(a.b_dm), pb);
         }
     }
 
@@ -218,6 +227,15 @@ __global__ __launch_bounds__(TX *TZ / 4, GRAD ? 4 : 1) void step2d_kernel(Step2D
         for (int i = 0; i < 4; ++i) {
             const float ed = ee[i] * a.dt;
             res[i] = fast_div(a.dt2 * lap[i] + 2.0f * mm[i] * uc[i] - mm[i] * oo[i] + ed * uc[i], mm[i] + ed);
+        }
+        if (BORN) {
+            const float bn[4] = {bn4.x, bn4.y, bn4.z, bn4.w}, bc[4] = {bc4.x, bc4.y, bc4.z, bc4.w},
+                        bo[4] = {bo4.x, bo4.y, bo4.z, bo4.w}, bd[4] = {bd4.x, bd4.y, bd4.z, bd4.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float utt = (bn[i] - 2.0f * bc[i] + bo[i]) * a.inv_dt2;
+                res[i] += fast_div(a.dt2 * (-bd[i] * utt), mm[i] + ee[i] * a.dt);
+            }
         }
         if (ninj > 0) {
             const float4 add = *reinterpret_cast<const float4 *>(&acc[4 * tid]);
@@ -282,9 +300,11 @@ template <int R, int TX, int TZ>
 static int launch_rt(const Plan &p, const Step2DArgs &a, int nblocks, hipStream_t stream)
 {
     if (a.um)
-        hipLaunchKernelGGL((step2d_kernel<R, TX, TZ, true>), dim3(nblocks), dim3(TX * TZ / 4), 0, stream, a);
+        hipLaunchKernelGGL((step2d_kernel<R, TX, TZ, 1>), dim3(nblocks), dim3(TX * TZ / 4), 0, stream, a);
+    else if (a.b_un)
+        hipLaunchKernelGGL((step2d_kernel<R, TX, TZ, 2>), dim3(nblocks), dim3(TX * TZ / 4), 0, stream, a);
     else
-        hipLaunchKernelGGL((step2d_kernel<R, TX, TZ, false>), dim3(nblocks), dim3(TX * TZ / 4), 0, stream, a);
+        hipLaunchKernelGGL((step2d_kernel<R, TX, TZ, 0>), dim3(nblocks), dim3(TX * TZ / 4), 0, stream, a);
     MIFWI_HIP(hipGetLastError());
     return MIFWI_OK;
 }

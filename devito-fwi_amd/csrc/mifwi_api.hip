@@ -771,11 +771,20 @@ static LoopCtx<T> make_ctx(const Plan &p, int nshots, bool grad)
     return c;
 }
 
+// Born source term of the scattered field (operators.py:263): background levels and dm
+template <typename T>
+struct BornTerm {
+    const T *un, *uc, *uo;   // u[time+1] (source already injected), u[time], u[time-1]; shot 0
+    long shot_stride;
+    const T *dm;             // haloed, shared by the shots
+};
+
 // One forward step: out = step(cur, old) + injected source term of `time`; with `interp` the
 // receivers sample `cur` into d_rec[time].
 template <typename T>
 static int forward_step(Plan &p, const LoopCtx<T> &c, const T *cur, const T *old, T *out, long shot_stride, int time,
-                        bool interp, int &launches, bool inject = true, T *copy = nullptr, long copy_stride = 0)
+                        bool interp, int &launches, bool inject = true, T *copy = nullptr, long copy_stride = 0,
+                        const BornTerm<T> *born = nullptr)
 {
     int rc;
     if (p.kind == 1) {
@@ -785,6 +794,10 @@ static int forward_step(Plan &p, const LoopCtx<T> &c, const T *cur, const T *old
         if (interp) set_interp(a, p.rec, p.d_rec);
         a.cur = (const float *)cur, a.old = (const float *)old, a.out = (float *)out, a.time = time;
         a.copy = (float *)copy, a.copy_shot_stride = copy_stride;
+        if (born) {
+            a.b_un = (const float *)born->un, a.b_uc = (const float *)born->uc, a.b_uo = (const float *)born->uo;
+            a.b_dm = (const float *)born->dm, a.b_shot_stride = born->shot_stride;
+        }
         if ((rc = launch_step2d(p, a, p.stream))) return rc;
         launches += 1;
         return MIFWI_OK;
@@ -795,6 +808,10 @@ static int forward_step(Plan &p, const LoopCtx<T> &c, const T *cur, const T *old
         if (inject) set_inject3(a, p.src, p);
         if (interp) set_interp3(a, p.rec, p.d_rec);
         a.cur = (const float *)cur, a.old = (const float *)old, a.out = (float *)out, a.time = time;
+        if (born) {
+            a.b_un = (const float *)born->un, a.b_uc = (const float *)born->uc, a.b_uo = (const float *)born->uo;
+            a.b_dm = (const float *)born->dm, a.b_shot_stride = born->shot_stride;
+        }
         if ((rc = launch_step3d(p, a, p.stream))) return rc;
         launches += 1;
         return MIFWI_OK;
@@ -807,6 +824,12 @@ static int forward_step(Plan &p, const LoopCtx<T> &c, const T *cur, const T *old
         launches += 1;
     }
     if ((rc = launch_step_generic<T>(p, c.k, sp, gp, c.nshots))) return rc;
+    if (born) {   // untiled path: the source term is its own pointwise launch
+        if ((rc = launch_born_source<T>(p, c.k, born->un, born->uc, born->uo, born->shot_stride, born->dm, out,
+                                        shot_stride, c.nshots, 0)))
+            return rc;
+        launches += 1;
+    }
     SparsePtrs<T> q{};
     if (inject) {
         q.inj = &p.src;
@@ -1188,18 +1211,15 @@ static int born(Plan &p, int nshots, const void *wavelet, int per_shot, const vo
     p.rot_u_valid = p.rot_v_valid = false;
     if ((rc = prepare_injection<T>(p, p.src, p.d_wavelet, nshots))) return rc;
     const LoopCtx<T> ctx = make_ctx<T>(p, nshots, false);
-    const int ghost = (ctx.k.fs && p.kind != 0) ? 1 : 0;
     auto enqueue = [&](int &launches) -> int {
         for (int time = 1; time <= nt - 2; ++time) {
             const long c = (long)(time % 3) * L.field, o = (long)((time + 2) % 3) * L.field,
                        n = (long)((time + 1) % 3) * L.field;
             int r;
             if ((r = forward_step<T>(p, ctx, bu + c, bu + o, bu + n, stride, time, false, launches, true))) return r;
-            if ((r = forward_step<T>(p, ctx, bU + c, bU + o, bU + n, stride, time, true, launches, false))) return r;
-            if ((r = launch_born_source<T>(p, ctx.k, bu + n, bu + c, bu + o, stride, (const T *)p.d_dm, bU + n, stride,
-                                           nshots, ghost)))
+            const BornTerm<T> bt{bu + n, bu + c, bu + o, stride, (const T *)p.d_dm};
+            if ((r = forward_step<T>(p, ctx, bU + c, bU + o, bU + n, stride, time, true, launches, false, nullptr, 0, &bt)))
                 return r;
-            launches += 1;
         }
         return MIFWI_OK;
     };
@@ -1207,8 +1227,8 @@ static int born(Plan &p, int nshots, const void *wavelet, int per_shot, const vo
     float ms = 0;
     const auto key = std::make_tuple(3, nshots, 0, 0, 0);
     if ((rc = timed_loop(p, &key, enqueue, launches, ms))) return rc;
-    // two propagations (20 B/pt each) + the source term (3 levels of u, dm, m, eta, U read+write)
-    fill_stats(p, ms, nt - 2, nshots, 72.0, launches, false);
+    // two propagations (20 B/pt each) + the source term's reads (3 levels of u, dm)
+    fill_stats(p, ms, nt - 2, nshots, 56.0, launches, false);
     p.rot_u_valid = p.rot_v_valid = true;
     if (rec_out && (rc = copy_any(p, rec_out, p.d_rec, (size_t)nshots * nt * p.cfg.nrec * sizeof(T)))) return rc;
     return finish(p);

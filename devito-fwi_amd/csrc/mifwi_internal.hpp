@@ -309,6 +309,10 @@ struct Step2DArgs {
     // second, streamed copy of `out` (the saved forward level), or null
     float *copy;
     long copy_shot_stride;
+    // Born source term (b_un == nullptr: none): the field being advanced is the scattered one and
+    // out += dt^2 * ( -dm * (b_un - 2 b_uc + b_uo) / dt^2 ) / ( m + eta dt )   (operators.py:263)
+    const float *b_un, *b_uc, *b_uo, *b_dm;
+    long b_shot_stride;
 };
 int launch_step2d(const Plan &p, const Step2DArgs &a, hipStream_t stream);
 
@@ -343,6 +347,10 @@ struct Step3DArgs {
     float *vals_out;
     int time, nt;
     int fs;   // free surface: keep the antisymmetric mirror of rows z = 1..R in the z halo of `out`
+    // Born source term (b_un == nullptr: none): the field being advanced is the scattered one and
+    // out += dt^2 * ( -dm * (b_un - 2 b_uc + b_uo) / dt^2 ) / ( m + eta dt )   (operators.py:263)
+    const float *b_un, *b_uc, *b_uo, *b_dm;
+    long b_shot_stride;
 };
 int launch_step3d(const Plan &p, const Step3DArgs &a, hipStream_t stream);
 int launch_eta_zero(const Plan &p, unsigned char *flags);
