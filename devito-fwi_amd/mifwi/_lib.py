@@ -189,8 +189,13 @@ class Plan(object):
         assert n == self.ngrid, "vp must cover the padded grid"
         self._check(self._lib.mifwi_set_model(self._h, pv, pd))
 
-    def set_geometry(self, src_coords, rec_coords, rec_per_shot=False):
-        sc = np.ascontiguousarray(src_coords, dtype=self.dtype).reshape(-1, self.nsrc, self.ndim)
+    def set_geometry(self, src_coords, rec_coords, rec_per_shot=False, nshots=None):
+        sc = np.ascontiguousarray(src_coords, dtype=self.dtype)
+        if self.nsrc == 0:      # no sources: the shot count cannot be read off the coordinates
+            nshots = int(nshots or (sc.shape[0] if sc.ndim == 3 else 1))
+            sc = np.zeros((nshots, 1, self.ndim), dtype=self.dtype)
+        else:
+            sc = sc.reshape(-1, self.nsrc, self.ndim)
         nshots = sc.shape[0]
         rc_ = np.ascontiguousarray(rec_coords, dtype=self.dtype)
         rc_ = rc_.reshape((nshots, self.nrec, self.ndim) if rec_per_shot else (self.nrec, self.ndim))

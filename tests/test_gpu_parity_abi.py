@@ -151,3 +151,71 @@ def test_checkpointed_gradient_is_bit_identical(mifwi, kind):
     with pytest.raises(mifwi.MifwiError):
         ck.read_wavefield(0, shot=0)          # levels are not stored one by one
     ck.close()
+
+
+@pytest.mark.parametrize("shape,so,flags", [((50, 41), 8, 0), ((50, 41), 8, 4), ((20, 23, 66), 8, 0)])
+def test_per_shot_receivers_and_wavelets(mifwi, shape, so, flags):
+    """Receiver tables and wavelets that differ from shot to shot (rec_per_shot / wavelet_per_shot of the
+    ABI): every shot against its own oracle run, forward, adjoint and gradient."""
+    case = Case(shape, (10.0,) * len(shape), nbl=6, space_order=so, nt=70, nshots=3, nrec=9, seed=21)
+    rng = np.random.default_rng(5)
+    dom = np.array([(n - 1) * 10.0 for n in shape])
+    recs = ((rng.random((3, 9, len(shape))) * 0.7 + 0.15) * dom).astype(np.float32)
+    wav = np.stack([case.wavelet * (1.0 + 0.5 * s) for s in range(3)]).astype(np.float32)
+    p = case.prob
+    plan = mifwi.Plan(p.shape_pad, p.spacing, p.origin_pad, so, case.nt, case.dt, 1, 9, max_shots=3, flags=flags)
+    plan.set_model(p.vp, p.damp)
+    plan.set_geometry(case.src, recs, rec_per_shot=True)
+    rec = plan.forward(wav, wavelet_per_shot=True, save=True)
+    refs = [p.forward(case.src[s], wav[s], recs[s], dt=case.dt, save=True) for s in range(3)]
+    for s in range(3):
+        assert rel_l2(rec[s], refs[s][0]) <= 1e-5, s
+    srca = plan.adjoint(rec)
+    grad = plan.gradient(rec)
+    for s in range(3):
+        assert rel_l2(srca[s], p.adjoint(case.src[s], recs[s], refs[s][0], dt=case.dt)) <= 1e-4, s
+        assert rel_l2(grad[s], p.gradient(recs[s], refs[s][0], refs[s][1], dt=case.dt)) <= 1e-4, s
+    plan.close()
+
+
+@pytest.mark.parametrize("flags", [0, 4])
+def test_points_on_and_beyond_the_grid_edge(mifwi, flags):
+    """Sources / receivers on the last cell of the padded grid, exactly on a grid line, and one cell outside
+    (the reference's generated code accepts indices -1..n, sa_01_iso_implementation1.ipynb:1255-1316)."""
+    case = Case((40, 36), (10.0, 10.0), nbl=5, space_order=4, nt=90, nshots=1, nrec=6, seed=3)
+    p = case.prob
+    lo = np.array(p.origin_pad)
+    hi = lo + (np.array(p.shape_pad) - 1) * 10.0
+    case.src[0, 0] = [200.0, 150.0]                              # exactly on grid lines
+    case.rec[:] = [[lo[0], 100.0], [hi[0], 120.0], [150.0, hi[1]], [lo[0] - 4.0, 90.0], [160.0, hi[1] + 6.0],
+                   [200.0, 150.0]]
+    plan = case.plan(mifwi, flags=flags)
+    rec = plan.forward(case.wavelet)
+    ref, _ = case.oracle_forward(0)
+    assert rel_l2(rec[0], ref) <= 1e-5
+    srca = plan.adjoint(rec)
+    assert rel_l2(srca[0], case.oracle_adjoint(0, ref)) <= 1e-4
+    plan.close()
+
+
+def test_no_receivers_and_no_sources(mifwi):
+    """nrec = 0: forward still propagates (wavefield equals the oracle's); nsrc = 0: adjoint runs."""
+    case = Case((38, 35), (10.0, 10.0), nbl=6, space_order=8, nt=60, nshots=1, nrec=5, seed=8)
+    p = case.prob
+    plan = mifwi.Plan(p.shape_pad, p.spacing, p.origin_pad, 8, case.nt, case.dt, 1, 0, max_shots=1)
+    plan.set_model(p.vp, p.damp)
+    plan.set_geometry(case.src, np.zeros((0, 2), np.float32))
+    rec = plan.forward(case.wavelet, save=True)
+    assert rec.shape == (1, case.nt, 0)
+    _, u = case.oracle_forward(0, save=True)
+    assert rel_l2(plan.read_wavefield(0), u) <= 1e-5
+    plan.close()
+    plan = mifwi.Plan(p.shape_pad, p.spacing, p.origin_pad, 8, case.nt, case.dt, 0, 5, max_shots=1)
+    plan.set_model(p.vp, p.damp)
+    plan.set_geometry(np.zeros((1, 0, 2), np.float32), case.rec)
+    data = np.random.default_rng(0).standard_normal((1, case.nt, 5)).astype(np.float32)
+    srca = plan.adjoint(data)
+    assert srca.shape == (1, case.nt, 0)
+    v = plan.read_wavefield(2)
+    assert np.isfinite(v).all() and np.abs(v).max() > 0
+    plan.close()
