@@ -219,3 +219,31 @@ def test_no_receivers_and_no_sources(mifwi):
     v = plan.read_wavefield(2)
     assert np.isfinite(v).all() and np.abs(v).max() > 0
     plan.close()
+
+
+def test_user_stream_async_and_device_buffers(mifwi):
+    """mifwi_set_stream + MIFWI_FLAG_ASYNC with inputs and outputs that live on the GPU (torch tensors):
+    same numbers as the synchronous host-buffer calls."""
+    import torch
+    case = Case((45, 38), (10.0, 12.5), nbl=9, space_order=8, nt=120, nshots=2, nrec=13, seed=4)
+    ref_plan = case.plan(mifwi)
+    rec_ref = ref_plan.forward(case.wavelet, save=True)
+    grad_ref, illum_ref = ref_plan.gradient(rec_ref, want_illum=True)
+    ref_plan.close()
+    dev = torch.device("cuda")
+    stream = torch.cuda.Stream()
+    plan = case.plan(mifwi, flags=mifwi.FLAG_ASYNC)
+    plan.set_stream(stream.cuda_stream)
+    with torch.cuda.stream(stream):
+        w = torch.from_numpy(case.wavelet).to(dev)
+        rec = torch.empty((2, case.nt, case.nrec), dtype=torch.float32, device=dev)
+        grad = torch.zeros((2,) + case.prob.shape_pad, dtype=torch.float32, device=dev)
+        illum = torch.zeros_like(grad)
+    stream.synchronize()
+    plan.forward(w, rec_out=rec, save=True)
+    plan.gradient(rec, grad=grad, illum=illum)
+    plan.synchronize()
+    assert np.array_equal(rec.cpu().numpy(), rec_ref)
+    assert np.array_equal(grad.cpu().numpy(), grad_ref)
+    assert np.array_equal(illum.cpu().numpy(), illum_ref)
+    plan.close()
