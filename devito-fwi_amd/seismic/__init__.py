@@ -8,3 +8,4 @@ from .model import *  # noqa
 from .source import *  # noqa
 from .preset_models import *  # noqa
 from .utils import *  # noqa
+from .plotting import *  # noqa

@@ -155,3 +155,23 @@ def test_qwasserstein_1d_closed_forms():
     with pytest.raises(NotImplementedError):
         qWasserstein(method='2d')
     assert Misfit(least_square)(np.ones(3), np.zeros(3))[0] == pytest.approx(1.5)
+
+
+def test_plotting_helpers_render(tmp_path):
+    """The drivers' figures (seismic/plotting.py of the reference) can be drawn headless."""
+    matplotlib = pytest.importorskip("matplotlib")
+    matplotlib.use("Agg")
+    import matplotlib.pyplot as plt
+    from seismic import demo_model, plot_velocity, plot_shotrecord, plot_image, plot_perturbation
+    model = demo_model('layers-isotropic', shape=(40, 30), spacing=(10., 10.), nbl=5, space_order=4)
+    other = demo_model('constant-isotropic', shape=(40, 30), spacing=(10., 10.), nbl=5, space_order=4, vp=2.0)
+    src = np.array([[200., 20.]])
+    rec = np.stack([np.linspace(0, 390, 12), np.full(12, 20.)], axis=1)
+    plot_velocity(model, source=src, receiver=rec, show=False)
+    plt.savefig(tmp_path / "v.png"); plt.clf()
+    plot_perturbation(model, model, show=False); plt.clf()
+    plot_shotrecord(np.random.default_rng(0).standard_normal((50, 12)), model, 0., 500., show=False); plt.clf()
+    plot_image(np.asarray(model.vp.data)[model.physical_slices], cmap="jet", show=False)
+    plt.savefig(tmp_path / "i.png"); plt.clf()
+    assert (tmp_path / "v.png").stat().st_size > 1000 and (tmp_path / "i.png").stat().st_size > 1000
+    del other
