@@ -152,8 +152,9 @@ def test_qwasserstein_1d_closed_forms():
     # the shift constant depends on min(f, g) only, so the perturbation leaves it unchanged
     corr = np.corrcoef(fd, adj2[idx, 0])[0, 1]
     assert corr > 0.9
+    w2d = qWasserstein(gamma=1.01, method='2d', num_steps=15, step_scale=1.)     # as the drivers build it
     with pytest.raises(NotImplementedError):
-        qWasserstein(method='2d')
+        w2d(f, g)
     assert Misfit(least_square)(np.ones(3), np.zeros(3))[0] == pytest.approx(1.5)
 
 
