@@ -172,7 +172,9 @@ def _batch_entry(geometry, shots):
     from mifwi import engine
     model = geometry.model
     model._initialize_bcs(bcs="damp")
-    nt = geometry.nt
+    # modelling always runs on the model's own time axis: the per-shot geometries the reference builds
+    # (fwi.py:73-76,185-188) do not inherit geometry.resample(), which only affects the misfit sampling
+    nt = _shot_geometry(geometry, 0).nt
     from mifwi import FLAG_FREE_SURFACE
     entry = engine.get_plan(model.grid.shape, model.spacing, model.grid.origin, model.space_order, nt,
                             model.critical_dt, 1, geometry.nrec, max_shots=len(shots), dtype=model.dtype,
@@ -362,13 +364,19 @@ def fwi_obj_single(geometry, obs, misfit_func, direct_wave=None, resample_dt=Non
             dw = deepcopy(direct_wave).resample(resample_dt)
     syn_data = pred.data
     obs_data = obs.data
+    pred_times = pred.time_values
+    # The modelling time step follows max(vp) of each model, so the resampled axes of observed and
+    # predicted data can differ by a sample once the model has been updated (the reference stops with
+    # a shape error there); compare them on the samples they share.
+    n = min(syn_data.shape[0], obs_data.shape[0], dw.data.shape[0] if direct_wave is not None else 1 << 30)
+    syn_data, obs_data, pred_times = syn_data[:n], obs_data[:n], pred_times[:n]
     if direct_wave is not None:
-        syn_data = syn_data - dw.data
-        obs_data = obs_data - dw.data
+        syn_data = syn_data - dw.data[:n]
+        obs_data = obs_data - dw.data[:n]
     fval, residual_data = misfit_func(syn_data, obs_data)
     residual = Receiver(name="rec", grid=geometry.model.grid, time_range=geometry.time_axis,
                         coordinates=geometry.rec_positions)
-    residual.data[:] = resample(residual_data, geometry.time_axis.time_values, pred.time_values)[:]
+    residual.data[:] = resample(residual_data, geometry.time_axis.time_values, pred_times)[:]
     illum, crop_grad = None, None
     if calc_grad:
         grad = Function(name="grad", grid=geometry.model.grid)

@@ -20,6 +20,9 @@ def demo_model(preset, **kwargs):
     vp = kwargs.pop('vp', 1.5)
     nlayers = kwargs.pop('nlayers', 3)
     fs = kwargs.pop('fs', False)
+    # The reference's presets build upstream Devito's SeismicModel (preset_models.py:5), which has no `dt`
+    # argument: a `dt=` given to demo_model (circle_fwi.py:70-75) does not change the CFL time step there.
+    kwargs.pop('dt', None)
     name = preset.lower()
 
     if name == 'constant-isotropic':

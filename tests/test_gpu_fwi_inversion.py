@@ -42,3 +42,45 @@ def test_marmousi_w2_and_nlcg_run(tmp_path, capsys):
     misfit = np.loadtxt(tmp_path / "log1" / "misfit")
     assert misfit.shape == (2, 2) and misfit[1, 0] < misfit[0, 0]
     assert np.isfinite(vp).all()
+
+
+def test_circle_workflow_with_resampled_traces(tmp_path, capsys):
+    """The set-up of the reference's circle_fwi.py:60-168 with fewer shots: demo_model ignores `dt`, so the
+    solver steps with the CFL time step (different for the true and the initial model) while the misfit
+    is taken on traces resampled to 1 ms (geometry.resample), which sends every shot through the
+    resampling branch of fwi_obj_single (fwi.py:140-160).  With these sizes both resampled axes have
+    1003 samples, as in the reference's own run."""
+    from seismic import demo_model, AcquisitionGeometry
+    from fwi import fm_multi, fwi_loss
+    from misfit import least_square
+    from optimize import LBFGS
+    from minimize import minimize
+    shape, spacing, nbl, so = (201, 201), (10., 10.), 40, 6
+    kw = dict(origin=(0, 0), shape=shape, spacing=spacing, space_order=so, nbl=nbl, dt=1.)
+    true_model = demo_model('circle-isotropic', vp_circle=3.6, vp_background=3, r=60, **kw)
+    init_model = demo_model('circle-isotropic', vp_circle=3, vp_background=3, r=60, **kw)
+    assert float(true_model.critical_dt) > 1.0                      # dt=1 was not taken over
+    nsrc = 3
+    src = np.empty((nsrc, 2))
+    src[:, 1] = np.linspace(0, true_model.domain_size[0], num=nsrc)
+    src[:, 0] = 20.
+    rec = np.empty((shape[0], 2))
+    rec[:, 1] = np.linspace(spacing[0], true_model.domain_size[0] - spacing[0], num=shape[0])
+    rec[:, 0] = 1980.
+    g1 = AcquisitionGeometry(true_model, rec, src, 0., 1000., f0=0.010, src_type='Ricker')
+    g0 = AcquisitionGeometry(init_model, rec, src, 0., 1000., f0=0.010, src_type='Ricker')
+    g1.resample(1.)
+    g0.resample(1.)
+    obs = fm_multi(g1, save=False)
+    # observed data live on the modelling axis (CFL step), not on the resampled one
+    assert obs[0].data.shape[0] != g1.nt and np.isclose(obs[0].time_range.step, float(true_model.critical_dt))
+    m0 = 1. / (np.full(shape, 3.0).reshape(-1).astype(np.float64)) ** 2
+    f0_, grad, res = fwi_loss(m0, g0, obs, least_square, None, None, True)
+    assert f0_ > 0 and np.isfinite(grad).all() and np.abs(grad).max() > 0
+    log = tmp_path / "log"
+    opt = LBFGS(memory=5, ls_method='Bracket', step_len_init=0.05, max_ls=5, log_path=str(log))
+    m = minimize(opt, maxIter=2, ftol=1e-5, gtol=1e-10, log_path=str(log)).run(
+        m0, g0, obs, least_square, None, None, True, [1.0 / 4.0 ** 2, 1.0 / 2.0 ** 2])
+    misfit = np.loadtxt(log / "misfit")
+    assert misfit[1, 0] < misfit[0, 0]
+    assert m.shape == m0.shape
