@@ -36,6 +36,9 @@
 
 #include <stdint.h>
 
+/* the only symbols the shared library exports */
+#define MIFWI_API __attribute__((visibility("default")))
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -109,28 +112,28 @@ typedef struct mifwi_stats {
     int64_t device_bytes;   /* device memory currently held by the plan                       */
 } mifwi_stats;
 
-int mifwi_version(void);
-const char *mifwi_last_error(void);
+MIFWI_API int mifwi_version(void);
+MIFWI_API const char *mifwi_last_error(void);
 
 /* Replaces: AcousticWaveSolver.__init__ + the (memoised) Operator construction,
  * seismic/acoustic/wavesolver.py:28-74. */
-int mifwi_plan_create(const mifwi_config *cfg, mifwi_plan **out);
-int mifwi_plan_destroy(mifwi_plan *plan);
+MIFWI_API int mifwi_plan_create(const mifwi_config *cfg, mifwi_plan **out);
+MIFWI_API int mifwi_plan_destroy(mifwi_plan *plan);
 
 /* Use an existing hipStream_t (e.g. the caller's framework stream) for all work of the plan. */
-int mifwi_set_stream(mifwi_plan *plan, void *hip_stream);
-int mifwi_synchronize(mifwi_plan *plan);
+MIFWI_API int mifwi_set_stream(mifwi_plan *plan, void *hip_stream);
+MIFWI_API int mifwi_synchronize(mifwi_plan *plan);
 
 /* Replaces: the `vp` and `damp` arguments of every Operator.apply
  * (seismic/acoustic/wavesolver.py:109,112; seismic/model.py:13-51,395-400).  vp in km/s and
  * damp are padded-grid arrays; m = 1/vp^2 is formed on the device. */
-int mifwi_set_model(mifwi_plan *plan, const void *vp, const void *damp);
+MIFWI_API int mifwi_set_model(mifwi_plan *plan, const void *vp, const void *damp);
 
 /* Replaces: the src_coords / rec_coords arguments (SparseTimeFunction.coordinates,
  * seismic/utils.py:147-186).  src_coords is (nshots, nsrc, ndim).  rec_coords is
  * (nrec, ndim) shared by all shots when rec_per_shot == 0, else (nshots, nrec, ndim).
  * Physical coordinates in the units of `spacing`, element type = plan dtype. */
-int mifwi_set_geometry(mifwi_plan *plan, int32_t nshots, const void *src_coords,
+MIFWI_API int mifwi_set_geometry(mifwi_plan *plan, int32_t nshots, const void *src_coords,
                        const void *rec_coords, int32_t rec_per_shot);
 
 /* Replaces: AcousticWaveSolver.forward -> op_fwd(save).apply(src, rec, u, vp, dt)
@@ -138,7 +141,7 @@ int mifwi_set_geometry(mifwi_plan *plan, int32_t nshots, const void *src_coords,
  * wavelet: (nt, nsrc) shared by all shots when wavelet_per_shot == 0, else (nshots, nt, nsrc).
  * rec_out: (nshots, nt, nrec) or NULL.  save != 0 keeps every time level on the device for
  * mifwi_gradient / mifwi_read_wavefield. */
-int mifwi_forward(mifwi_plan *plan, int32_t nshots, const void *wavelet, int32_t wavelet_per_shot,
+MIFWI_API int mifwi_forward(mifwi_plan *plan, int32_t nshots, const void *wavelet, int32_t wavelet_per_shot,
                   void *rec_out, int32_t save);
 
 /* Replaces: AcousticWaveSolver.jacobian (= born) -> op_born().apply(dm, src, rec, u, U, vp, dt)
@@ -147,13 +150,13 @@ int mifwi_forward(mifwi_plan *plan, int32_t nshots, const void *wavelet, int32_t
  * -dm * u.dt2; rec_out (nshots, nt, nrec) receives the samples of U.  dm: (grid), one model
  * perturbation (of 1/vp^2) shared by all shots.  Afterwards mifwi_read_wavefield(which = 1) gives
  * the last three levels of u and which = 2 those of U. */
-int mifwi_born(mifwi_plan *plan, int32_t nshots, const void *wavelet, int32_t wavelet_per_shot,
+MIFWI_API int mifwi_born(mifwi_plan *plan, int32_t nshots, const void *wavelet, int32_t wavelet_per_shot,
                const void *dm, void *rec_out);
 
 /* Replaces: AcousticWaveSolver.adjoint -> op_adj().apply(srca, rec, v, vp, dt)
  * (seismic/acoustic/wavesolver.py:116-151; seismic/acoustic/operators.py:143-180).
  * rec_in (nshots, nt, nrec); srca_out (nshots, nt, nsrc). */
-int mifwi_adjoint(mifwi_plan *plan, int32_t nshots, const void *rec_in, void *srca_out);
+MIFWI_API int mifwi_adjoint(mifwi_plan *plan, int32_t nshots, const void *rec_in, void *srca_out);
 
 /* Replaces: AcousticWaveSolver.jacobian_adjoint (= gradient) -> op_grad().apply(rec, grad, v, u, vp, dt)
  * (seismic/acoustic/wavesolver.py:153-205; seismic/acoustic/operators.py:183-225), using the
@@ -161,7 +164,7 @@ int mifwi_adjoint(mifwi_plan *plan, int32_t nshots, const void *rec_in, void *sr
  * residual (nshots, nt, nrec).  grad (nshots, grid): per-shot gradients on the padded grid;
  * with accumulate != 0 the result is ADDED to the caller's array (Devito's `Inc`), else stored.
  * illum: NULL or (nshots, grid), receives sum_t u^2 (fwi.py:170 of the reference). */
-int mifwi_gradient(mifwi_plan *plan, int32_t nshots, const void *residual, void *grad,
+MIFWI_API int mifwi_gradient(mifwi_plan *plan, int32_t nshots, const void *residual, void *grad,
                    int32_t accumulate, void *illum);
 
 /* Fused per-shot objective of fwi.py:131-173 with the L2 misfit (misfit/misfit.py:5-9):
@@ -169,7 +172,7 @@ int mifwi_gradient(mifwi_plan *plan, int32_t nshots, const void *residual, void 
  * device.  obs (nshots, nt, nrec); fval (nshots) doubles; grad/illum as in mifwi_gradient
  * (stored, not accumulated; either may be NULL, grad == NULL skips the backward pass);
  * residual_out / syn_out NULL or (nshots, nt, nrec). */
-int mifwi_l2_misfit_gradient(mifwi_plan *plan, int32_t nshots, const void *wavelet,
+MIFWI_API int mifwi_l2_misfit_gradient(mifwi_plan *plan, int32_t nshots, const void *wavelet,
                              int32_t wavelet_per_shot, const void *obs, double *fval, void *grad,
                              void *illum, void *residual_out, void *syn_out);
 
@@ -182,21 +185,21 @@ int mifwi_l2_misfit_gradient(mifwi_plan *plan, int32_t nshots, const void *wavel
  * both fields, rec_out (nshots, nt, nrec) samples u + v.  mifwi_tti_adjoint replaces op_adj().apply
  * (wavesolver.py:208-215): rec_in (nshots, nt, nrec) -> srca_out (nshots, nt, nsrc).  The last three
  * levels of (u, v) and (p, r) are readable through mifwi_read_wavefield which = 3, 4 and 5, 6. */
-int mifwi_tti_set_model(mifwi_plan *plan, const void *epsilon, const void *delta, const void *theta,
+MIFWI_API int mifwi_tti_set_model(mifwi_plan *plan, const void *epsilon, const void *delta, const void *theta,
                         const void *phi);
-int mifwi_tti_forward(mifwi_plan *plan, int32_t nshots, const void *wavelet, int32_t wavelet_per_shot,
+MIFWI_API int mifwi_tti_forward(mifwi_plan *plan, int32_t nshots, const void *wavelet, int32_t wavelet_per_shot,
                       void *rec_out);
-int mifwi_tti_adjoint(mifwi_plan *plan, int32_t nshots, const void *rec_in, void *srca_out);
+MIFWI_API int mifwi_tti_adjoint(mifwi_plan *plan, int32_t nshots, const void *rec_in, void *srca_out);
 
 /* Access to wavefield time levels of one shot, `u.data[first:first+count]` in the reference
  * (TimeFunction(save=nt), seismic/acoustic/wavesolver.py:104-106).  which = 0: saved forward
  * field (level index = time).  which = 1: the three rotating buffers of the last non-saving
  * forward run, which = 2: those of the last adjoint/gradient run (level index = time % 3). */
-int mifwi_read_wavefield(mifwi_plan *plan, int32_t which, int32_t shot, int32_t first, int32_t count,
+MIFWI_API int mifwi_read_wavefield(mifwi_plan *plan, int32_t which, int32_t shot, int32_t first, int32_t count,
                          void *out);
-int mifwi_write_wavefield(mifwi_plan *plan, int32_t shot, int32_t first, int32_t count, const void *in);
+MIFWI_API int mifwi_write_wavefield(mifwi_plan *plan, int32_t shot, int32_t first, int32_t count, const void *in);
 
-int mifwi_get_stats(mifwi_plan *plan, mifwi_stats *out);
+MIFWI_API int mifwi_get_stats(mifwi_plan *plan, mifwi_stats *out);
 
 #ifdef __cplusplus
 }
