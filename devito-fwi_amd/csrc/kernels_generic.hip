@@ -247,13 +247,13 @@ struct SparseDev {
     const int32_t *uc_cell, *uc_ptr, *uc_count, *e_point;
     const T *e_w;
     int inj_kmax, inj_npoint, inj_per_shot, nb_inj;
-    T *field_inj;
+    T *field_inj, *field_inj2;
     const T *vals_inj;
     // interpolation
     const int32_t *pt_idx;
     const T *pt_w;
     int itp_npoint, itp_ncorner, itp_per_shot;
-    const T *field_int;
+    const T *field_int, *field_int2;
     T *vals_out;
     long shot_stride;
     const T *m;
@@ -276,7 +276,9 @@ __global__ __launch_bounds__(256) void sparse_kernel(SparseDev<T> d)
         T sum = 0;
         for (int e = ptr[kk]; e < ptr[kk + 1]; ++e) sum += ew[e] * vals[ep[e]];
         const long cell = d.uc_cell[(long)tab * d.inj_kmax + kk];
-        d.field_inj[(long)shot * d.shot_stride + cell] += sum * d.dt2 / d.m[cell];
+        const T term = sum * d.dt2 / d.m[cell];
+        d.field_inj[(long)shot * d.shot_stride + cell] += term;
+        if (d.field_inj2) d.field_inj2[(long)shot * d.shot_stride + cell] += term;
     } else {
         const int tab = d.itp_per_shot ? shot : 0;
         const int pnt = (blockIdx.x - d.nb_inj) * 256 + threadIdx.x;
@@ -285,7 +287,12 @@ __global__ __launch_bounds__(256) void sparse_kernel(SparseDev<T> d)
         const T *w = d.pt_w + ((long)tab * d.itp_npoint + pnt) * d.itp_ncorner;
         const T *f = d.field_int + (long)shot * d.shot_stride;
         T sum = 0;
-        for (int c = 0; c < d.itp_ncorner; ++c) sum += w[c] * f[idx[c]];
+        if (d.field_int2) {
+            const T *f2 = d.field_int2 + (long)shot * d.shot_stride;
+            for (int c = 0; c < d.itp_ncorner; ++c) sum += w[c] * (f[idx[c]] + f2[idx[c]]);
+        } else {
+            for (int c = 0; c < d.itp_ncorner; ++c) sum += w[c] * f[idx[c]];
+        }
         d.vals_out[((long)shot * d.nt + d.time) * d.itp_npoint + pnt] = sum;
     }
 }
@@ -345,6 +352,7 @@ int launch_sparse(const Plan &p, const SparsePtrs<T> &sp, int nshots)
         d.inj_per_shot = sp.inj->per_shot;
         d.nb_inj = (sp.inj->max_count + 255) / 256;
         d.field_inj = sp.field_inj;
+        d.field_inj2 = sp.field_inj2;
         d.vals_inj = sp.vals_inj;
     }
     if (sp.itp && sp.itp->npoint > 0) {
@@ -354,6 +362,7 @@ int launch_sparse(const Plan &p, const SparsePtrs<T> &sp, int nshots)
         d.itp_ncorner = sp.itp->ncorner;
         d.itp_per_shot = sp.itp->per_shot;
         d.field_int = sp.field_int;
+        d.field_int2 = sp.field_int2;
         d.vals_out = sp.vals_out;
         nb_itp = (sp.itp->npoint + 255) / 256;
     }

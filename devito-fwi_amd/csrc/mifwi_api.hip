@@ -1314,7 +1314,7 @@ static int tti_set_model(Plan &p, const void *eps, const void *delta, const void
         if ((rc = dev_alloc(p, &p.tti_par, 6 * fb, true))) return rc;
         if ((rc = dev_alloc(p, &p.tti_fwd, 2 * S * 3 * fb, true))) return rc;
         if ((rc = dev_alloc(p, &p.tti_adj, 2 * S * 3 * fb, true))) return rc;
-        if ((rc = dev_alloc(p, &p.tti_tmp, 5 * S * fb, true))) return rc;
+        if ((rc = dev_alloc(p, &p.tti_tmp, 4 * S * fb, true))) return rc;
     }
     const StepConsts<T> k = make_consts<T>(p);
     T *par = (T *)p.tti_par;
@@ -1366,11 +1366,10 @@ static int tti_run(Plan &p, int nshots, int mode)
     T *fu = (T *)(mode == 0 ? p.tti_fwd : p.tti_adj);
     T *fv = fu + S * stride;
     T *tmp = (T *)p.tti_tmp;
-    T *wA = tmp, *wB = tmp + S * L.field, *gzA = tmp + 2 * S * L.field, *gzB = tmp + 3 * S * L.field,
-      *sum = tmp + 4 * S * L.field;
+    T *wA = tmp, *wB = tmp + S * L.field, *gzA = tmp + 2 * S * L.field, *gzB = tmp + 3 * S * L.field;
     MIFWI_HIP(hipMemsetAsync(fu, 0, (size_t)nshots * stride * sizeof(T), p.stream));
     MIFWI_HIP(hipMemsetAsync(fv, 0, (size_t)nshots * stride * sizeof(T), p.stream));
-    MIFWI_HIP(hipMemsetAsync(tmp, 0, (size_t)5 * S * L.field * sizeof(T), p.stream));
+    MIFWI_HIP(hipMemsetAsync(tmp, 0, (size_t)4 * S * L.field * sizeof(T), p.stream));
     const SparseSet &inj = mode == 0 ? p.src : p.rec, &itp = mode == 0 ? p.rec : p.src;
     const T *vals_in = (const T *)(mode == 0 ? p.d_wavelet : p.d_res);
     T *vals_out = (T *)(mode == 0 ? p.d_rec : p.d_srca);
@@ -1385,23 +1384,15 @@ static int tti_run(Plan &p, int nshots, int mode)
             const long od = (long)((time + (mode == 0 ? 2 : 1)) % 3) * L.field;
             TtiLevels<T> lv{fu + c, fu + od, fv + c, fv + od, fu + nx, fv + nx, stride};
             int r;
-            if ((r = launch_tti_step<T>(p, k, q, mode == 0, lv, wA, wB, gzA, gzB, sum, nshots, launches))) return r;
+            if ((r = launch_tti_step<T>(p, k, q, mode == 0, lv, wA, wB, gzA, gzB, nshots, launches))) return r;
+            // one launch: the same terms into both new fields, receivers sample the sum of the current ones
             SparsePtrs<T> sq{};
-            sq.inj = &inj, sq.field_inj = fu + nx, sq.vals_inj = vals_in;
-            sq.itp = &itp, sq.field_int = sum, sq.vals_out = vals_out;
+            sq.inj = &inj, sq.field_inj = fu + nx, sq.field_inj2 = fv + nx, sq.vals_inj = vals_in;
+            sq.itp = &itp, sq.field_int = fu + c, sq.field_int2 = fv + c, sq.vals_out = vals_out;
             sq.shot_stride = stride;
             sq.m = (const T *)p.m, sq.time = time, sq.nt = nt, sq.dt2 = k.dt2;
-            // the sampled field (sum) is one level per shot: its own stride
-            SparsePtrs<T> s1 = sq;
-            s1.itp = nullptr;
-            if ((r = launch_sparse<T>(p, s1, nshots))) return r;              // inject into the first field
-            s1.field_inj = fv + nx;
-            if ((r = launch_sparse<T>(p, s1, nshots))) return r;              // ... and into the second
-            SparsePtrs<T> s2 = sq;
-            s2.inj = nullptr;
-            s2.shot_stride = L.field;
-            if ((r = launch_sparse<T>(p, s2, nshots))) return r;              // sample u + v
-            launches += 3;
+            if ((r = launch_sparse<T>(p, sq, nshots))) return r;
+            launches += 1;
         }
         return MIFWI_OK;
     };

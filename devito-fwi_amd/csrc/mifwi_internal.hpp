@@ -122,7 +122,7 @@ struct Plan {
     void *d_grad = nullptr, *d_illum = nullptr; // [max_shots][field] haloed accumulators
     void *d_t4 = nullptr, *d_w2 = nullptr;   // OT4 scratch fields, [max_shots][field] each
     // TTI state: parameter fields [6][field], field pairs [2][max_shots][3][field] (forward u,v / adjoint p,r),
-    // scratch [5][max_shots][field] (wA, wB, gzA, gzB, sum)
+    // scratch [4][max_shots][field] (wA, wB, gzA, gzB)
     void *tti_par = nullptr, *tti_fwd = nullptr, *tti_adj = nullptr, *tti_tmp = nullptr;
     bool tti_fwd_valid = false, tti_adj_valid = false;
     // Injected terms of every time step, formed once before a time loop of the tiled kernels:
@@ -198,9 +198,11 @@ template <typename T>
 struct SparsePtrs {
     const SparseSet *inj;      // null: no injection
     T *field_inj;              // shot 0 level base
+    T *field_inj2 = nullptr;   // optional second field receiving the same terms (TTI)
     const T *vals_inj;         // [shots][nt][inj->npoint]
     const SparseSet *itp;      // null: no interpolation
     const T *field_int;        // shot 0 level base
+    const T *field_int2 = nullptr; // optional second field added to the sampled one (TTI: u + v)
     T *vals_out;               // [shots][nt][itp->npoint]
     long shot_stride;
     const T *m;
@@ -261,7 +263,7 @@ template <typename T>
 int launch_tti_param(const Plan &p, const StepConsts<T> &k, const T *dense, T *haloed, int mode, T halo_value);
 template <typename T>
 int launch_tti_step(const Plan &p, const StepConsts<T> &k, const TtiParams<T> &q, int fwd, const TtiLevels<T> &lv,
-                    T *wA, T *wB, T *gzA, T *gzB, T *sum, int nshots, int &launches);
+                    T *wA, T *wB, T *gzA, T *gzB, int nshots, int &launches);
 
 // ---- tiled 2-D fast path (kernels_tiled2d.hip) -------------------------------------------------
 // LDS row pitch (floats) of a staged tile.  ds_read_b128 serves a wave in four groups of 16 lanes
