@@ -158,11 +158,12 @@ __global__ __launch_bounds__(256) void tti_step_kernel(StepConsts<T> k, TtiParam
 }
 
 // ------------------------------------------------------------------------------------------------
-// Tiled 2-D TTI step (float32): one launch advances both fields of every shot.  A 32 x 32 tile of the
-// two stencilled fields is staged in LDS with a halo of R, the angle fields with a halo of p = R/2;
-// Gz of both fields is formed on the tile extended by p and kept in LDS, then every thread updates four
-// points (rows ty, ty+8, ty+16, ty+24 of column tz) from LDS.  Same arithmetic, in the same order, as
-// tti_gz_kernel + tti_step_kernel.
+// Tiled 2-D TTI step (float32): one launch advances both fields of every shot, adds the injected
+// terms and samples the receivers.  A TX x TZ tile of the two stencilled fields is staged in LDS with a
+// halo of R; Gz of both fields is formed on the tile extended by p = R/2 and its products with cos and
+// sin of the tilt are kept in LDS (the angle fields themselves go through registers only); then every
+// thread updates TX*TZ/256 points from LDS.  Same arithmetic, in the same order, as tti_gz_kernel +
+// tti_step_kernel.
 // ------------------------------------------------------------------------------------------------
 struct Tti2DArgs {
     const float *ucur, *uold, *vcur, *vold;
@@ -174,80 +175,165 @@ struct Tti2DArgs {
     int n1, n2;
     long s1, off0;
     int ntx, ntz, nshots;
+    // injection into both new fields (slot_count == nullptr: none): terms winj[shot][time][slot_base[tile] + j]
+    const int32_t *slot_count, *slot_local, *slot_base;
+    int inj_cap, inj_per_shot;
+    const float *winj;
+    long winj_stride;
+    // interpolation of ucur + vcur (pt_idx == nullptr: none)
+    const int32_t *pt_idx;
+    const float *pt_w;
+    int itp_npoint, itp_per_shot;
+    float *vals_out;
+    int time, nt;
 };
 
-template <int R, bool FWD>
+// LDS row pitch.  With TZ = 32 a wave covers rows ty and ty + 4 of the tile, so the two half-waves hit
+// disjoint halves of the 64 banks when 4 * pitch = 32 (mod 64), i.e. pitch = 8 (mod 16).  With TZ = 64 a
+// wave is one row and any pitch is conflict free.
+__host__ __device__ constexpr int tti_pitch(int n, int tz)
+{
+    return tz == 32 ? (n + 7) / 16 * 16 + 8 : n;
+}
+
+template <int R, int TX, int TZ, bool FWD>
 __global__ __launch_bounds__(256) void tti2d_kernel(Tti2DArgs a)
 {
-    constexpr int TX = 32, TZ = 32, P = R / 2;
-    constexpr int WA = TZ + 2 * R + 1, HA = TX + 2 * R;      // +1: odd pitch spreads the rows over the banks
-    constexpr int WE = TZ + 2 * P + 1, HE = TX + 2 * P;
-    __shared__ float sA[HA * WA], sB[HA * WA], sgA[HE * WE], sgB[HE * WE], sct[HE * WE], sst[HE * WE];
+    constexpr int P = R / 2, NT = 256;
+    constexpr int LA = TZ + 2 * R, HA = TX + 2 * R;   // staged fields: logical row length, rows
+    constexpr int LE = TZ + 2 * P, HE = TX + 2 * P;   // extended tile of Gz
+    constexpr int WA = tti_pitch(LA, TZ), WE = tti_pitch(LE, TZ);
+    constexpr int NPT = TX * TZ / NT;                 // points per thread
+    constexpr int RP = NT / TZ;                       // tile rows covered by one pass of the block
+    constexpr int NEXT = (HE * LE + NT - 1) / NT;     // Gz points per thread
+    constexpr int NSTG = (HA * LA + NT - 1) / NT;     // staged points per thread
+    static_assert(WA >= LA && WE >= LE, "pitch");
+    __shared__ float sA[HA * WA], sB[HA * WA];
+    __shared__ float cgA[HE * WE], sgA[HE * WE], cgB[HE * WE], sgB[HE * WE];
+    __shared__ float acc[TX * TZ];
+
     const int tid = threadIdx.x;
-    const int bid = blockIdx.x;
+    const int nitp_blocks = a.pt_idx ? ((a.itp_npoint + NT - 1) / NT) * a.nshots : 0;
+    int bid = blockIdx.x;
+    if (bid < nitp_blocks) {
+        // ---- interpolation role: the sum of the two current fields at the sparse points ----------
+        const int shot = bid % a.nshots;
+        const int pnt = (bid / a.nshots) * NT + tid;
+        if (pnt >= a.itp_npoint) return;
+        const int tab = a.itp_per_shot ? shot : 0;
+        const int4 idx = *reinterpret_cast<const int4 *>(a.pt_idx + ((long)tab * a.itp_npoint + pnt) * 4);
+        const float4 w = *reinterpret_cast<const float4 *>(a.pt_w + ((long)tab * a.itp_npoint + pnt) * 4);
+        const float *f = a.ucur + (long)shot * a.shot_stride;
+        const float *g = a.vcur + (long)shot * a.shot_stride;
+        const float sum = w.x * (f[idx.x] + g[idx.x]) + w.y * (f[idx.y] + g[idx.y]) + w.z * (f[idx.z] + g[idx.z]) +
+                          w.w * (f[idx.w] + g[idx.w]);
+        a.vals_out[((long)shot * a.nt + a.time) * a.itp_npoint + pnt] = sum;
+        return;
+    }
+    bid -= nitp_blocks;
+
     const int shot = bid % a.nshots;
     const int tile = bid / a.nshots;
     const int tile_x = tile / a.ntz, tile_z = tile - tile_x * a.ntz;
     const int x0 = tile_x * TX, z0 = tile_z * TZ;
-    const float *ucur = a.ucur + (long)shot * a.shot_stride;
-    const float *vcur = a.vcur + (long)shot * a.shot_stride;
+    const long sbase = (long)shot * a.shot_stride;
+    const float *ucur = a.ucur + sbase, *vcur = a.vcur + sbase;
+    const int inj_tab = a.inj_per_shot ? shot : 0;
+    const int ninj = a.slot_count ? a.slot_count[(long)inj_tab * (a.ntx * a.ntz) + tile] : 0;   // block-uniform
 
-    // ---- stage the two fields (halo R) and the angle fields (halo P) ------------------------------
-    for (int e = tid; e < HA * (WA - 1); e += 256) {
-        const int r = e / (WA - 1), c = e - r * (WA - 1);
-        const int gx = x0 - R + r, gz = z0 - R + c;
-        float fa = 0.f, fb = 0.f;
-        if (gx < a.n1 + R && gz < a.n2 + R) {
-            const long i = a.off0 + (long)gx * a.s1 + gz;
-            const float uu = ucur[i], vv = vcur[i];
+    // ---- this thread's points: start their loads first ----------------------------------------------
+    const int tz = tid & (TZ - 1);
+    const int ty = TZ == 32 ? (tid >> 6) + 4 * ((tid >> 5) & 1) : (tid >> 6);
+    const int z = z0 + tz;
+    float pm[NPT], pe[NPT], pet[NPT], pdl[NPT], puo[NPT], pvo[NPT], puc[NPT], pvc[NPT];
+#pragma unroll
+    for (int k = 0; k < NPT; ++k) {
+        const int x = x0 + ty + RP * k;
+        pm[k] = 1.f, pe[k] = 0.f, pet[k] = 1.f, pdl[k] = 1.f, puo[k] = 0.f, pvo[k] = 0.f, puc[k] = 0.f, pvc[k] = 0.f;
+        if (x < a.n1 && z < a.n2) {
+            const long i = a.off0 + (long)x * a.s1 + z;
+            pm[k] = a.m[i], pe[k] = a.eta[i];
+            puo[k] = a.uold[sbase + i], pvo[k] = a.vold[sbase + i];
             if (FWD) {
-                fa = uu, fb = vv;
+                pet[k] = a.et[i], pdl[k] = a.dl[i];
             } else {
-                const float et = a.et[i], dl = a.dl[i];
-                fa = et * uu + dl * vv;
-                fb = dl * uu + vv;
+                puc[k] = ucur[i], pvc[k] = vcur[i];
             }
         }
-        sA[r * WA + c] = fa;
-        sB[r * WA + c] = fb;
     }
-    for (int e = tid; e < HE * (WE - 1); e += 256) {
-        const int r = e / (WE - 1), c = e - r * (WE - 1);
+    // angle fields at this thread's points of the extended tile
+    float ect[NEXT], est[NEXT];
+#pragma unroll
+    for (int n = 0; n < NEXT; ++n) {
+        const int e = tid + NT * n;
+        const int r = e / LE, c = e - r * LE;
         const int gx = x0 - P + r, gz = z0 - P + c;
-        float ct = 1.f, st = 0.f;
-        if (gx < a.n1 + P && gz < a.n2 + P) {
+        ect[n] = 1.f, est[n] = 0.f;
+        if (e < HE * LE && gx < a.n1 + P && gz < a.n2 + P) {
             const long i = a.off0 + (long)gx * a.s1 + gz;
-            ct = a.ct[i], st = a.st[i];
+            ect[n] = a.ct[i], est[n] = a.st[i];
         }
-        sct[r * WE + c] = ct;
-        sst[r * WE + c] = st;
+    }
+
+    // ---- stage the two stencilled fields (halo R) --------------------------------------------------
+#pragma unroll
+    for (int n = 0; n < NSTG; ++n) {
+        const int e = tid + NT * n;
+        const int r = e / LA, c = e - r * LA;
+        const int gx = x0 - R + r, gz = z0 - R + c;
+        if (e < HA * LA) {
+            float fa = 0.f, fb = 0.f;
+            if (gx < a.n1 + R && gz < a.n2 + R) {
+                const long i = a.off0 + (long)gx * a.s1 + gz;
+                const float uu = ucur[i], vv = vcur[i];
+                if (FWD) {
+                    fa = uu, fb = vv;
+                } else {
+                    const float et = a.et[i], dl = a.dl[i];
+                    fa = et * uu + dl * vv;
+                    fb = dl * uu + vv;
+                }
+            }
+            sA[r * WA + c] = fa;
+            sB[r * WA + c] = fb;
+        }
+    }
+    if (ninj > 0) {
+        for (int j = tid; j < TX * TZ; j += NT) acc[j] = 0.f;
+        __syncthreads();
+        const long tslot = (long)inj_tab * (a.ntx * a.ntz) + tile;
+        const float *w = a.winj + ((long)shot * a.nt + a.time) * a.winj_stride + a.slot_base[tslot];
+        for (int j = tid; j < ninj; j += NT) acc[a.slot_local[tslot * a.inj_cap + j]] = w[j];
     }
     __syncthreads();
 
-    // ---- Gz of both fields on the tile extended by P -----------------------------------------------
-    for (int e = tid; e < HE * (WE - 1); e += 256) {
-        const int r = e / (WE - 1), c = e - r * (WE - 1);
-        const int ia = (r + R - P) * WA + (c + R - P);
-        float dxa = 0.f, dza = 0.f, dxb = 0.f, dzb = 0.f;
+    // ---- Gz of both fields on the extended tile, times cos and sin of the tilt ------------------------
 #pragma unroll
-        for (int j = 1; j <= P; ++j) {
-            dxa += a.a1[j] * (sA[ia + j * WA] - sA[ia - j * WA]);
-            dza += a.a1[j] * (sA[ia + j] - sA[ia - j]);
-            dxb += a.a1[j] * (sB[ia + j * WA] - sB[ia - j * WA]);
-            dzb += a.a1[j] * (sB[ia + j] - sB[ia - j]);
+    for (int n = 0; n < NEXT; ++n) {
+        const int e = tid + NT * n;
+        const int r = e / LE, c = e - r * LE;
+        if (e < HE * LE) {
+            const int ia = (r + R - P) * WA + (c + R - P);
+            float dxa = 0.f, dza = 0.f, dxb = 0.f, dzb = 0.f;
+#pragma unroll
+            for (int j = 1; j <= P; ++j) {
+                dxa += a.a1[j] * (sA[ia + j * WA] - sA[ia - j * WA]);
+                dza += a.a1[j] * (sA[ia + j] - sA[ia - j]);
+                dxb += a.a1[j] * (sB[ia + j * WA] - sB[ia - j * WA]);
+                dzb += a.a1[j] * (sB[ia + j] - sB[ia - j]);
+            }
+            const float ga = -(est[n] * (dxa * a.ihx) + ect[n] * (dza * a.ihz));
+            const float gb = -(est[n] * (dxb * a.ihx) + ect[n] * (dzb * a.ihz));
+            cgA[r * WE + c] = ect[n] * ga, sgA[r * WE + c] = est[n] * ga;
+            cgB[r * WE + c] = ect[n] * gb, sgB[r * WE + c] = est[n] * gb;
         }
-        const float ct = sct[r * WE + c], st = sst[r * WE + c];
-        sgA[r * WE + c] = -(st * (dxa * a.ihx) + ct * (dza * a.ihz));
-        sgB[r * WE + c] = -(st * (dxb * a.ihx) + ct * (dzb * a.ihz));
     }
     __syncthreads();
 
-    // ---- update four points per thread ----------------------------------------------------------------
-    const int tz = tid & 31, ty = tid >> 5;
-    const int z = z0 + tz;
+    // ---- update this thread's points ----------------------------------------------------------------------
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int row = ty + 8 * k;
+    for (int k = 0; k < NPT; ++k) {
+        const int row = ty + RP * k;
         const int x = x0 + row;
         if (x >= a.n1 || z >= a.n2) continue;
         const int ia = (row + R) * WA + tz + R;
@@ -260,43 +346,56 @@ __global__ __launch_bounds__(256) void tti2d_kernel(Tti2DArgs a)
         float sa = 0.f, sb = 0.f;
 #pragma unroll
         for (int j = 1; j <= P; ++j) {
-            float ta = a.a1[j] * (sct[ie + j] * sgA[ie + j] - sct[ie - j] * sgA[ie - j]) * a.ihz;
-            ta += a.a1[j] * (sst[ie + j * WE] * sgA[ie + j * WE] - sst[ie - j * WE] * sgA[ie - j * WE]) * a.ihx;
+            float ta = a.a1[j] * (cgA[ie + j] - cgA[ie - j]) * a.ihz;
+            ta += a.a1[j] * (sgA[ie + j * WE] - sgA[ie - j * WE]) * a.ihx;
             sa += ta;
-            float tb = a.a1[j] * (sct[ie + j] * sgB[ie + j] - sct[ie - j] * sgB[ie - j]) * a.ihz;
-            tb += a.a1[j] * (sst[ie + j * WE] * sgB[ie + j * WE] - sst[ie - j * WE] * sgB[ie - j * WE]) * a.ihx;
+            float tb = a.a1[j] * (cgB[ie + j] - cgB[ie - j]) * a.ihz;
+            tb += a.a1[j] * (sgB[ie + j * WE] - sgB[ie - j * WE]) * a.ihx;
             sb += tb;
         }
-        const float X = lap - (-sa), Y = -sb;
-        const long i = a.off0 + (long)x * a.s1 + z;
-        const long si = (long)shot * a.shot_stride + i;
+        const float X = lap + sa, Y = -sb;   // Gxx = laplace - Gzz with Gzz = -sa
         float H0 = X, Hz = Y;
+        float uc = puc[k], vc = pvc[k];
         if (FWD) {
-            const float et = a.et[i], dl = a.dl[i];
-            H0 = et * X + dl * Y;
-            Hz = dl * X + Y;
+            H0 = pet[k] * X + pdl[k] * Y;
+            Hz = pdl[k] * X + Y;
+            uc = sA[ia], vc = sB[ia];
         }
-        const float uc = a.ucur[si], vc = a.vcur[si];
-        const float mz = a.m[i], ed = a.eta[i] * a.dt;
-        a.uout[si] = (a.dt2 * H0 + 2.0f * mz * uc - mz * a.uold[si] + ed * uc) / (mz + ed);
-        a.vout[si] = (a.dt2 * Hz + 2.0f * mz * vc - mz * a.vold[si] + ed * vc) / (mz + ed);
+        const float mz = pm[k], ed = pe[k] * a.dt;
+        float un = (a.dt2 * H0 + 2.0f * mz * uc - mz * puo[k] + ed * uc) / (mz + ed);
+        float vn = (a.dt2 * Hz + 2.0f * mz * vc - mz * pvo[k] + ed * vc) / (mz + ed);
+        if (ninj > 0) {
+            const float add = acc[row * TZ + tz];
+            un += add, vn += add;
+        }
+        const long si = sbase + a.off0 + (long)x * a.s1 + z;
+        a.uout[si] = un;
+        a.vout[si] = vn;
     }
 }
 
 template <int R>
 static int launch_tti2d_r(const Plan &p, const Tti2DArgs &a, int fwd)
 {
-    const int nblocks = a.ntx * a.ntz * a.nshots;
-    if (fwd)
-        hipLaunchKernelGGL((tti2d_kernel<R, true>), dim3(nblocks), dim3(256), 0, p.stream, a);
-    else
-        hipLaunchKernelGGL((tti2d_kernel<R, false>), dim3(nblocks), dim3(256), 0, p.stream, a);
+    const int nblocks = a.ntx * a.ntz * a.nshots + (a.pt_idx ? ((a.itp_npoint + 255) / 256) * a.nshots : 0);
+    if (p.tile_tz == 64) {
+        if (fwd) hipLaunchKernelGGL((tti2d_kernel<R, 16, 64, true>), dim3(nblocks), dim3(256), 0, p.stream, a);
+        else hipLaunchKernelGGL((tti2d_kernel<R, 16, 64, false>), dim3(nblocks), dim3(256), 0, p.stream, a);
+    } else {
+        if (fwd) hipLaunchKernelGGL((tti2d_kernel<R, 32, 32, true>), dim3(nblocks), dim3(256), 0, p.stream, a);
+        else hipLaunchKernelGGL((tti2d_kernel<R, 32, 32, false>), dim3(nblocks), dim3(256), 0, p.stream, a);
+    }
     MIFWI_HIP(hipGetLastError());
     return MIFWI_OK;
 }
 
+bool tti2d_available(const Plan &p)
+{
+    return p.kind == 1 && ((p.tile_tx == 32 && p.tile_tz == 32) || (p.tile_tx == 16 && p.tile_tz == 64));
+}
+
 static int launch_tti2d(const Plan &p, const StepConsts<float> &k, const TtiParams<float> &q, int fwd,
-                        const TtiLevels<float> &lv, int nshots)
+                        const TtiLevels<float> &lv, int nshots, const Step2DArgs &sp)
 {
     Tti2DArgs a{};
     a.ucur = lv.ucur, a.uold = lv.uold, a.vcur = lv.vcur, a.vold = lv.vold, a.uout = lv.uout, a.vout = lv.vout;
@@ -309,7 +408,11 @@ static int launch_tti2d(const Plan &p, const StepConsts<float> &k, const TtiPara
     a.ihx = q.ih[1], a.ihz = q.ih[2];
     a.dt = k.dt, a.dt2 = k.dt2;
     a.n1 = k.n1, a.n2 = k.n2, a.s1 = k.s1, a.off0 = k.off0;
-    a.ntx = (k.n1 + 31) / 32, a.ntz = (k.n2 + 31) / 32, a.nshots = nshots;
+    a.ntx = p.ntx, a.ntz = p.ntz, a.nshots = nshots;
+    a.slot_count = sp.slot_count, a.slot_local = sp.slot_local, a.slot_base = sp.slot_base;
+    a.inj_cap = sp.inj_cap, a.inj_per_shot = sp.inj_per_shot, a.winj = sp.winj, a.winj_stride = sp.winj_stride;
+    a.pt_idx = sp.pt_idx, a.pt_w = sp.pt_w, a.itp_npoint = sp.itp_npoint, a.itp_per_shot = sp.itp_per_shot;
+    a.vals_out = sp.vals_out, a.time = sp.time, a.nt = sp.nt;
     switch (p.L.R) {
         case 2: return launch_tti2d_r<2>(p, a, fwd);
         case 4: return launch_tti2d_r<4>(p, a, fwd);
@@ -340,12 +443,12 @@ static int launch_tti_step_r(const Plan &p, const StepConsts<T> &k, const TtiPar
 // into wA, wB first.  Launch count is added to `launches`.
 template <typename T>
 int launch_tti_step(const Plan &p, const StepConsts<T> &k, const TtiParams<T> &q, int fwd, const TtiLevels<T> &lv,
-                    T *wA, T *wB, T *gzA, T *gzB, int nshots, int &launches)
+                    T *wA, T *wB, T *gzA, T *gzB, int nshots, int &launches, const Step2DArgs *sparse2d)
 {
     if constexpr (std::is_same<T, float>::value) {
-        if (p.kind == 1) {   // tiled 2-D path: one launch for both fields
+        if (sparse2d) {   // tiled 2-D path: one launch for both fields and the sparse terms
             launches += 1;
-            return launch_tti2d(p, k, q, fwd, lv, nshots);
+            return launch_tti2d(p, k, q, fwd, lv, nshots, *sparse2d);
         }
     }
     const int e = q.p, e0 = p.L.ndim == 3 ? e : 0;
@@ -379,8 +482,8 @@ int launch_tti_step(const Plan &p, const StepConsts<T> &k, const TtiParams<T> &q
     return MIFWI_EINVAL;
 }
 template int launch_tti_step<float>(const Plan &, const StepConsts<float> &, const TtiParams<float> &, int,
-                                    const TtiLevels<float> &, float *, float *, float *, float *, int, int &);
+                                    const TtiLevels<float> &, float *, float *, float *, float *, int, int &, const Step2DArgs *);
 template int launch_tti_step<double>(const Plan &, const StepConsts<double> &, const TtiParams<double> &, int,
-                                     const TtiLevels<double> &, double *, double *, double *, double *, int, int &);
+                                     const TtiLevels<double> &, double *, double *, double *, double *, int, int &, const Step2DArgs *);
 
 }  // namespace mifwi

@@ -1376,6 +1376,11 @@ static int tti_run(Plan &p, int nshots, int mode)
     MIFWI_HIP(hipMemsetAsync(vals_out, 0, (size_t)nshots * nt * std::max(1, itp.npoint) * sizeof(T), p.stream));
     const StepConsts<T> k = make_consts<T>(p);
     const TtiParams<T> q = tti_params<T>(p);
+    const bool tiled = std::is_same<T, float>::value && tti2d_available(p);
+    if (tiled) {
+        int r;
+        if ((r = prepare_injection<T>(p, inj, vals_in, nshots))) return r;
+    }
     auto enqueue = [&](int &launches) -> int {
         for (int step = 1; step <= nt - 2; ++step) {
             const int time = mode == 0 ? step : nt - 1 - step;
@@ -1384,7 +1389,15 @@ static int tti_run(Plan &p, int nshots, int mode)
             const long od = (long)((time + (mode == 0 ? 2 : 1)) % 3) * L.field;
             TtiLevels<T> lv{fu + c, fu + od, fv + c, fv + od, fu + nx, fv + nx, stride};
             int r;
-            if ((r = launch_tti_step<T>(p, k, q, mode == 0, lv, wA, wB, gzA, gzB, nshots, launches))) return r;
+            if (tiled) {
+                Step2DArgs sa{};
+                set_inject(sa, inj, p);
+                set_interp(sa, itp, vals_out);
+                sa.time = time, sa.nt = nt;
+                if ((r = launch_tti_step<T>(p, k, q, mode == 0, lv, wA, wB, gzA, gzB, nshots, launches, &sa))) return r;
+                continue;
+            }
+            if ((r = launch_tti_step<T>(p, k, q, mode == 0, lv, wA, wB, gzA, gzB, nshots, launches, nullptr))) return r;
             // one launch: the same terms into both new fields, receivers sample the sum of the current ones
             SparsePtrs<T> sq{};
             sq.inj = &inj, sq.field_inj = fu + nx, sq.field_inj2 = fv + nx, sq.vals_inj = vals_in;

@@ -261,9 +261,13 @@ struct TtiLevels {
 // (mode 1: 1+2x, 2: sqrt(1+2x), 3: cos, 4: sin); dense == null leaves the constant
 template <typename T>
 int launch_tti_param(const Plan &p, const StepConsts<T> &k, const T *dense, T *haloed, int mode, T halo_value);
+struct Step2DArgs;
+// sparse2d != null (float plans for which tti2d_available): the tiled 2-D kernel, which also adds the
+// injected terms and samples the receivers described by the injection/interpolation members of *sparse2d
 template <typename T>
 int launch_tti_step(const Plan &p, const StepConsts<T> &k, const TtiParams<T> &q, int fwd, const TtiLevels<T> &lv,
-                    T *wA, T *wB, T *gzA, T *gzB, int nshots, int &launches);
+                    T *wA, T *wB, T *gzA, T *gzB, int nshots, int &launches, const Step2DArgs *sparse2d);
+bool tti2d_available(const Plan &p);
 
 // ---- tiled 2-D fast path (kernels_tiled2d.hip) -------------------------------------------------
 // LDS row pitch (floats) of a staged tile.  ds_read_b128 serves a wave in four groups of 16 lanes
