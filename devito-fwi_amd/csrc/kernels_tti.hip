@@ -481,6 +481,47 @@ int launch_tti_step(const Plan &p, const StepConsts<T> &k, const TtiParams<T> &q
     set_error("TTI needs space_order divisible by 4");
     return MIFWI_EINVAL;
 }
+// ------------------------------------------------------------------------------------------------
+// Zero-lag correlation of the TTI gradient (seismic/tti/operators.py:631), one thread per point.
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void tti_grad_kernel(StepConsts<T> k, const T *su, const T *sv, long level_stride,
+                                                       long s_shot_stride, const T *pc, const T *rc,
+                                                       long a_shot_stride, T *grad, long g_shot_stride)
+{
+    const int i2 = blockIdx.x * 64 + threadIdx.x;
+    const int i1 = blockIdx.y * 4 + threadIdx.y;
+    const int shot = blockIdx.z / k.n0;
+    const int i0 = blockIdx.z - shot * k.n0;
+    if (i2 >= k.n2 || i1 >= k.n1) return;
+    const long i = k.off0 + (long)i0 * k.s0 + (long)i1 * k.s1 + i2;
+    const T *u = su + (long)shot * s_shot_stride + i, *v = sv + (long)shot * s_shot_stride + i;
+    const T utt = (u[level_stride] - T(2) * u[0] + u[-level_stride]) * k.inv_dt2;
+    const T vtt = (v[level_stride] - T(2) * v[0] + v[-level_stride]) * k.inv_dt2;
+    const long a = (long)shot * a_shot_stride + i;
+    grad[(long)shot * g_shot_stride + i] += -(utt * pc[a] + vtt * rc[a]);
+}
+
+template <typename T>
+int launch_tti_grad(const Plan &p, const StepConsts<T> &k, const T *su, const T *sv, long level_stride, long s_shot_stride,
+                    const T *pc, const T *rc, long a_shot_stride, T *grad, long g_shot_stride, int nshots)
+{
+    if ((long)nshots * k.n0 > 65535) {
+        set_error("TTI gradient kernel: nshots * shape[0] exceeds the grid z limit");
+        return MIFWI_EINVAL;
+    }
+    dim3 block(64, 4, 1);
+    dim3 grid((k.n2 + 63) / 64, (k.n1 + 3) / 4, (unsigned)(nshots * k.n0));
+    hipLaunchKernelGGL((tti_grad_kernel<T>), grid, block, 0, p.stream, k, su, sv, level_stride, s_shot_stride, pc, rc,
+                       a_shot_stride, grad, g_shot_stride);
+    MIFWI_HIP(hipGetLastError());
+    return MIFWI_OK;
+}
+template int launch_tti_grad<float>(const Plan &, const StepConsts<float> &, const float *, const float *, long, long,
+                                    const float *, const float *, long, float *, long, int);
+template int launch_tti_grad<double>(const Plan &, const StepConsts<double> &, const double *, const double *, long, long,
+                                     const double *, const double *, long, double *, long, int);
+
 template int launch_tti_step<float>(const Plan &, const StepConsts<float> &, const TtiParams<float> &, int,
                                     const TtiLevels<float> &, float *, float *, float *, float *, int, int &, const Step2DArgs *);
 template int launch_tti_step<double>(const Plan &, const StepConsts<double> &, const TtiParams<double> &, int,

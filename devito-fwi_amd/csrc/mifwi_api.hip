@@ -168,6 +168,7 @@ static void destroy(Plan *p)
     dev_free(p->tti_fwd);
     dev_free(p->tti_adj);
     dev_free(p->tti_tmp);
+    dev_free(p->tti_save);
     dev_free(p->d_t4);
     dev_free(p->d_w2);
     dev_free(p->d_dense);
@@ -1355,76 +1356,137 @@ static TtiParams<T> tti_params(const Plan &p)
     return q;
 }
 
-// mode 0: forward (d_wavelet -> d_rec), mode 1: adjoint (d_res -> d_srca)
+// One TTI step of both fields of every shot: the step itself, injection of `inj` (values vals_in) into
+// both new fields and sampling of the sum of the current fields at `itp` (either may be null).
 template <typename T>
-static int tti_run(Plan &p, int nshots, int mode)
+struct TtiLoop {
+    Plan &p;
+    int nshots;
+    StepConsts<T> k;
+    TtiParams<T> q;
+    bool tiled;
+    T *wA, *wB, *gzA, *gzB;
+
+    TtiLoop(Plan &plan, int n) : p(plan), nshots(n), k(make_consts<T>(plan)), q(tti_params<T>(plan))
+    {
+        tiled = std::is_same<T, float>::value && tti2d_available(plan);
+        const long S = plan.cfg.max_shots;
+        T *tmp = (T *)plan.tti_tmp;
+        wA = tmp, wB = tmp + S * plan.L.field, gzA = tmp + 2 * S * plan.L.field, gzB = tmp + 3 * S * plan.L.field;
+    }
+    // the tiled kernel reads precomputed injection terms: form them before the loop is enqueued
+    int prepare(const SparseSet *inj, const T *vals_in)
+    {
+        MIFWI_HIP(hipMemsetAsync(p.tti_tmp, 0, (size_t)4 * p.cfg.max_shots * p.L.field * sizeof(T), p.stream));
+        if (tiled && inj) return prepare_injection<T>(p, *inj, vals_in, nshots);
+        return MIFWI_OK;
+    }
+    int step(bool fwd, const TtiLevels<T> &lv, const SparseSet *inj, const T *vals_in, const SparseSet *itp,
+             T *vals_out, int time, int &launches)
+    {
+        int r;
+        if (tiled) {
+            Step2DArgs sa{};
+            if (inj) set_inject(sa, *inj, p);
+            if (itp) set_interp(sa, *itp, vals_out);
+            sa.time = time, sa.nt = p.cfg.nt;
+            return launch_tti_step<T>(p, k, q, fwd, lv, wA, wB, gzA, gzB, nshots, launches, &sa);
+        }
+        if ((r = launch_tti_step<T>(p, k, q, fwd, lv, wA, wB, gzA, gzB, nshots, launches, nullptr))) return r;
+        if (!inj && !itp) return MIFWI_OK;
+        SparsePtrs<T> sq{};
+        if (inj) sq.inj = inj, sq.field_inj = lv.uout, sq.field_inj2 = lv.vout, sq.vals_inj = vals_in;
+        if (itp) sq.itp = itp, sq.field_int = lv.ucur, sq.field_int2 = lv.vcur, sq.vals_out = vals_out;
+        sq.shot_stride = lv.shot_stride;
+        sq.m = (const T *)p.m, sq.time = time, sq.nt = p.cfg.nt, sq.dt2 = k.dt2;
+        if ((r = launch_sparse<T>(p, sq, nshots))) return r;
+        launches += 1;
+        return MIFWI_OK;
+    }
+};
+
+// rotating levels of a field pair: level (time + shift) % 3
+template <typename T>
+static TtiLevels<T> tti_rot(T *fu, T *fv, long field, int time, bool fwd)
+{
+    const long c = (long)(time % 3) * field;
+    const long nx = (long)((time + (fwd ? 1 : 2)) % 3) * field;
+    const long od = (long)((time + (fwd ? 2 : 1)) % 3) * field;
+    return TtiLevels<T>{fu + c, fu + od, fv + c, fv + od, fu + nx, fv + nx, 3L * field};
+}
+
+static int tti_check(Plan &p)
 {
     if (!p.tti_par) return fail(MIFWI_ESTATE, "mifwi_tti_set_model has not been called");
+    return MIFWI_OK;
+}
+
+// mode 0: forward (d_wavelet -> d_rec; save keeps every level of both fields), mode 1: adjoint (d_res -> d_srca)
+template <typename T>
+static int tti_run(Plan &p, int nshots, int mode, int save)
+{
+    int rc;
+    if ((rc = tti_check(p))) return rc;
     const Layout &L = p.L;
     const int nt = p.cfg.nt;
-    const long S = p.cfg.max_shots, stride = 3L * L.field;
-    T *fu = (T *)(mode == 0 ? p.tti_fwd : p.tti_adj);
+    const long S = p.cfg.max_shots;
+    if (save && !p.tti_save) {
+        const size_t need = (size_t)2 * S * nt * L.field * sizeof(T);
+        size_t free_b = 0, total_b = 0;
+        MIFWI_HIP(hipMemGetInfo(&free_b, &total_b));
+        if ((double)need > 0.9 * (double)free_b)
+            return fail(MIFWI_ENOMEM, "saving both TTI fields needs " + std::to_string(need >> 20) +
+                                          " MiB of device memory (no checkpointing on this path): use fewer shots per call");
+        clear_graphs(p);
+        if ((rc = dev_alloc(p, &p.tti_save, need, true))) return rc;
+    }
+    if (save) p.tti_save_valid = false;
+    const long stride = save ? (long)nt * L.field : 3L * L.field;
+    T *fu = save ? (T *)p.tti_save : (T *)(mode == 0 ? p.tti_fwd : p.tti_adj);
     T *fv = fu + S * stride;
-    T *tmp = (T *)p.tti_tmp;
-    T *wA = tmp, *wB = tmp + S * L.field, *gzA = tmp + 2 * S * L.field, *gzB = tmp + 3 * S * L.field;
-    MIFWI_HIP(hipMemsetAsync(fu, 0, (size_t)nshots * stride * sizeof(T), p.stream));
-    MIFWI_HIP(hipMemsetAsync(fv, 0, (size_t)nshots * stride * sizeof(T), p.stream));
-    MIFWI_HIP(hipMemsetAsync(tmp, 0, (size_t)4 * S * L.field * sizeof(T), p.stream));
+    if (!save) {
+        MIFWI_HIP(hipMemsetAsync(fu, 0, (size_t)nshots * stride * sizeof(T), p.stream));
+        MIFWI_HIP(hipMemsetAsync(fv, 0, (size_t)nshots * stride * sizeof(T), p.stream));
+    }   // saved levels 0 and 1 and every halo are never written: they keep the zeros of the allocation
     const SparseSet &inj = mode == 0 ? p.src : p.rec, &itp = mode == 0 ? p.rec : p.src;
     const T *vals_in = (const T *)(mode == 0 ? p.d_wavelet : p.d_res);
     T *vals_out = (T *)(mode == 0 ? p.d_rec : p.d_srca);
     MIFWI_HIP(hipMemsetAsync(vals_out, 0, (size_t)nshots * nt * std::max(1, itp.npoint) * sizeof(T), p.stream));
-    const StepConsts<T> k = make_consts<T>(p);
-    const TtiParams<T> q = tti_params<T>(p);
-    const bool tiled = std::is_same<T, float>::value && tti2d_available(p);
-    if (tiled) {
-        int r;
-        if ((r = prepare_injection<T>(p, inj, vals_in, nshots))) return r;
-    }
+    TtiLoop<T> loop(p, nshots);
+    if ((rc = loop.prepare(&inj, vals_in))) return rc;
     auto enqueue = [&](int &launches) -> int {
         for (int step = 1; step <= nt - 2; ++step) {
             const int time = mode == 0 ? step : nt - 1 - step;
-            const long c = (long)(time % 3) * L.field;
-            const long nx = (long)((time + (mode == 0 ? 1 : 2)) % 3) * L.field;
-            const long od = (long)((time + (mode == 0 ? 2 : 1)) % 3) * L.field;
-            TtiLevels<T> lv{fu + c, fu + od, fv + c, fv + od, fu + nx, fv + nx, stride};
-            int r;
-            if (tiled) {
-                Step2DArgs sa{};
-                set_inject(sa, inj, p);
-                set_interp(sa, itp, vals_out);
-                sa.time = time, sa.nt = nt;
-                if ((r = launch_tti_step<T>(p, k, q, mode == 0, lv, wA, wB, gzA, gzB, nshots, launches, &sa))) return r;
-                continue;
+            TtiLevels<T> lv = tti_rot<T>(fu, fv, L.field, time, mode == 0);
+            if (save) {
+                const long c = (long)time * L.field;
+                lv = TtiLevels<T>{fu + c, fu + c - L.field, fv + c, fv + c - L.field, fu + c + L.field, fv + c + L.field, stride};
             }
-            if ((r = launch_tti_step<T>(p, k, q, mode == 0, lv, wA, wB, gzA, gzB, nshots, launches, nullptr))) return r;
-            // one launch: the same terms into both new fields, receivers sample the sum of the current ones
-            SparsePtrs<T> sq{};
-            sq.inj = &inj, sq.field_inj = fu + nx, sq.field_inj2 = fv + nx, sq.vals_inj = vals_in;
-            sq.itp = &itp, sq.field_int = fu + c, sq.field_int2 = fv + c, sq.vals_out = vals_out;
-            sq.shot_stride = stride;
-            sq.m = (const T *)p.m, sq.time = time, sq.nt = nt, sq.dt2 = k.dt2;
-            if ((r = launch_sparse<T>(p, sq, nshots))) return r;
-            launches += 1;
+            int r;
+            if ((r = loop.step(mode == 0, lv, &inj, vals_in, &itp, vals_out, time, launches))) return r;
         }
         return MIFWI_OK;
     };
-    int launches = 0, rc;
+    int launches = 0;
     float ms = 0;
-    const auto key = std::make_tuple(4 + mode, nshots, 0, 0, 0);
+    const auto key = std::make_tuple(4 + mode, nshots, save, 0, 0);
     if ((rc = timed_loop(p, &key, enqueue, launches, ms))) return rc;
     fill_stats(p, ms, nt - 2, nshots, 2 * 20.0 + 6 * 4.0, launches, mode == 1);
-    (mode == 0 ? p.tti_fwd_valid : p.tti_adj_valid) = true;
+    if (save) {
+        p.tti_save_valid = true, p.tti_save_shots = nshots;
+    } else {
+        (mode == 0 ? p.tti_fwd_valid : p.tti_adj_valid) = true;
+    }
     return MIFWI_OK;
 }
 
 template <typename T>
-static int tti_forward(Plan &p, int nshots, const void *wavelet, int per_shot, void *rec_out)
+static int tti_forward(Plan &p, int nshots, const void *wavelet, int per_shot, void *rec_out, int save)
 {
     int rc;
     if ((rc = check_run(p, nshots))) return rc;
     if ((rc = upload_wavelet<T>(p, nshots, wavelet, per_shot))) return rc;
-    if ((rc = tti_run<T>(p, nshots, 0))) return rc;
+    if ((rc = tti_run<T>(p, nshots, 0, save))) return rc;
     if (rec_out && (rc = copy_any(p, rec_out, p.d_rec, (size_t)nshots * p.cfg.nt * p.cfg.nrec * sizeof(T)))) return rc;
     return finish(p);
 }
@@ -1436,8 +1498,102 @@ static int tti_adjoint(Plan &p, int nshots, const void *rec_in, void *srca_out)
     if ((rc = check_run(p, nshots))) return rc;
     if (!rec_in) return fail(MIFWI_EINVAL, "rec_in is null");
     if ((rc = copy_any(p, p.d_res, rec_in, (size_t)nshots * p.cfg.nt * p.cfg.nrec * sizeof(T)))) return rc;
-    if ((rc = tti_run<T>(p, nshots, 1))) return rc;
+    if ((rc = tti_run<T>(p, nshots, 1, 0))) return rc;
     if (srca_out && (rc = copy_any(p, srca_out, p.d_srca, (size_t)nshots * p.cfg.nt * p.cfg.nsrc * sizeof(T)))) return rc;
+    return finish(p);
+}
+
+// Linearised TTI modelling (seismic/tti/operators.py:529-587): background fields in tti_fwd, scattered
+// fields in tti_adj, all four advanced in one time loop.
+template <typename T>
+static int tti_born(Plan &p, int nshots, const void *wavelet, int per_shot, const void *dm, void *rec_out)
+{
+    int rc;
+    if ((rc = check_run(p, nshots))) return rc;
+    if ((rc = tti_check(p))) return rc;
+    if (!dm) return fail(MIFWI_EINVAL, "dm is null");
+    if ((rc = upload_wavelet<T>(p, nshots, wavelet, per_shot))) return rc;
+    const Layout &L = p.L;
+    const int nt = p.cfg.nt;
+    const long S = p.cfg.max_shots, stride = 3L * L.field;
+    if (!p.d_dm && (rc = dev_alloc(p, &p.d_dm, (size_t)L.field * sizeof(T), true))) return rc;
+    if ((rc = copy_any(p, p.d_dense, dm, (size_t)L.ngrid * sizeof(T)))) return rc;
+    if ((rc = launch_pack<T>(p, (const T *)p.d_dense, (T *)p.d_dm, L.field, 1))) return rc;
+    T *bu = (T *)p.tti_fwd, *bv = bu + S * stride, *dU = (T *)p.tti_adj, *dV = dU + S * stride;
+    for (T *f : {bu, bv, dU, dV}) MIFWI_HIP(hipMemsetAsync(f, 0, (size_t)nshots * stride * sizeof(T), p.stream));
+    MIFWI_HIP(hipMemsetAsync(p.d_rec, 0, (size_t)nshots * nt * std::max(1, p.cfg.nrec) * sizeof(T), p.stream));
+    p.tti_fwd_valid = p.tti_adj_valid = false;
+    TtiLoop<T> loop(p, nshots);
+    if ((rc = loop.prepare(&p.src, (const T *)p.d_wavelet))) return rc;
+    auto enqueue = [&](int &launches) -> int {
+        for (int time = 1; time <= nt - 2; ++time) {
+            const TtiLevels<T> b = tti_rot<T>(bu, bv, L.field, time, true), d = tti_rot<T>(dU, dV, L.field, time, true);
+            int r;
+            if ((r = loop.step(true, b, &p.src, (const T *)p.d_wavelet, nullptr, nullptr, time, launches))) return r;
+            if ((r = loop.step(true, d, nullptr, nullptr, &p.rec, (T *)p.d_rec, time, launches))) return r;
+            // qu = -dm u0.dt2, qv = -dm v0.dt2 (u0.dt2 after the injection into u0[t+1])
+            if ((r = launch_born_source<T>(p, loop.k, b.uout, b.ucur, b.uold, stride, (const T *)p.d_dm, d.uout, stride,
+                                           nshots, 0)))
+                return r;
+            if ((r = launch_born_source<T>(p, loop.k, b.vout, b.vcur, b.vold, stride, (const T *)p.d_dm, d.vout, stride,
+                                           nshots, 0)))
+                return r;
+            launches += 2;
+        }
+        return MIFWI_OK;
+    };
+    int launches = 0;
+    float ms = 0;
+    const auto key = std::make_tuple(6, nshots, 0, 0, 0);
+    if ((rc = timed_loop(p, &key, enqueue, launches, ms))) return rc;
+    fill_stats(p, ms, nt - 2, nshots, 2 * (2 * 20.0 + 6 * 4.0) + 2 * 16.0, launches, false);
+    p.tti_fwd_valid = p.tti_adj_valid = true;
+    if (rec_out && (rc = copy_any(p, rec_out, p.d_rec, (size_t)nshots * nt * p.cfg.nrec * sizeof(T)))) return rc;
+    return finish(p);
+}
+
+// Adjoint of the TTI Jacobian (seismic/tti/operators.py:590-639) on the levels kept by tti_forward(save).
+template <typename T>
+static int tti_gradient(Plan &p, int nshots, const void *residual, void *grad, int accumulate)
+{
+    int rc;
+    if ((rc = check_run(p, nshots))) return rc;
+    if ((rc = tti_check(p))) return rc;
+    if (!residual || !grad) return fail(MIFWI_EINVAL, "residual or grad is null");
+    if (!p.tti_save_valid || p.tti_save_shots < nshots)
+        return fail(MIFWI_ESTATE, "no saved TTI wavefields: call mifwi_tti_forward with save = 1 first");
+    const Layout &L = p.L;
+    const int nt = p.cfg.nt;
+    const long S = p.cfg.max_shots, stride = 3L * L.field, sstride = (long)nt * L.field;
+    if ((rc = copy_any(p, p.d_res, residual, (size_t)nshots * nt * p.cfg.nrec * sizeof(T)))) return rc;
+    if (!p.d_grad && (rc = dev_alloc(p, &p.d_grad, (size_t)S * L.field * sizeof(T), true))) return rc;
+    MIFWI_HIP(hipMemsetAsync(p.d_grad, 0, (size_t)nshots * L.field * sizeof(T), p.stream));
+    T *bp = (T *)p.tti_adj, *br = bp + S * stride;
+    MIFWI_HIP(hipMemsetAsync(bp, 0, (size_t)nshots * stride * sizeof(T), p.stream));
+    MIFWI_HIP(hipMemsetAsync(br, 0, (size_t)nshots * stride * sizeof(T), p.stream));
+    p.tti_adj_valid = false;
+    const T *su = (const T *)p.tti_save, *sv = su + S * sstride;
+    TtiLoop<T> loop(p, nshots);
+    if ((rc = loop.prepare(&p.rec, (const T *)p.d_res))) return rc;
+    auto enqueue = [&](int &launches) -> int {
+        for (int time = nt - 2; time >= 1; --time) {
+            const TtiLevels<T> a = tti_rot<T>(bp, br, L.field, time, false);
+            int r;
+            if ((r = loop.step(false, a, &p.rec, (const T *)p.d_res, nullptr, nullptr, time, launches))) return r;
+            if ((r = launch_tti_grad<T>(p, loop.k, su + (long)time * L.field, sv + (long)time * L.field, L.field, sstride,
+                                        a.ucur, a.vcur, stride, (T *)p.d_grad, L.field, nshots)))
+                return r;
+            launches += 1;
+        }
+        return MIFWI_OK;
+    };
+    int launches = 0;
+    float ms = 0;
+    const auto key = std::make_tuple(7, nshots, 0, 0, 0);
+    if ((rc = timed_loop(p, &key, enqueue, launches, ms))) return rc;
+    fill_stats(p, ms, nt - 2, nshots, 2 * 20.0 + 6 * 4.0 + 2 * 4.0 + 8.0, launches, true);
+    p.tti_adj_valid = true;
+    if ((rc = deliver_grid<T>(p, p.d_grad, grad, nshots, accumulate))) return rc;
     return finish(p);
 }
 
@@ -1466,8 +1622,12 @@ static int read_wavefield(Plan &p, int which, int shot, int first, int count, vo
         const int second = (which - 3) & 1;
         base = pair + ((long)second * p.cfg.max_shots + shot) * 3 * p.L.field;
         nlev = 3;
+    } else if (which == 7 || which == 8) {
+        if (!p.tti_save_valid || shot >= p.tti_save_shots) return fail(MIFWI_ESTATE, "no saved TTI wavefield for this shot");
+        base = (const T *)p.tti_save + ((long)(which - 7) * p.cfg.max_shots + shot) * p.cfg.nt * p.L.field;
+        nlev = p.cfg.nt;
     } else {
-        return fail(MIFWI_EINVAL, "which must be 0..6");
+        return fail(MIFWI_EINVAL, "which must be 0..8");
     }
     if (first < 0 || count < 0 || first + count > nlev) return fail(MIFWI_EINVAL, "level range out of bounds");
     int rc;
@@ -1639,17 +1799,33 @@ int mifwi_tti_set_model(mifwi_plan *plan, const void *epsilon, const void *delta
     return DISPATCH(tti_set_model<float>(p, epsilon, delta, theta, phi), tti_set_model<double>(p, epsilon, delta, theta, phi));
 }
 
-int mifwi_tti_forward(mifwi_plan *plan, int32_t nshots, const void *wavelet, int32_t wavelet_per_shot, void *rec_out)
+int mifwi_tti_forward(mifwi_plan *plan, int32_t nshots, const void *wavelet, int32_t wavelet_per_shot, void *rec_out,
+                      int32_t save)
 {
     PLAN_OR_FAIL(plan);
-    return DISPATCH(tti_forward<float>(p, nshots, wavelet, wavelet_per_shot, rec_out),
-                    tti_forward<double>(p, nshots, wavelet, wavelet_per_shot, rec_out));
+    return DISPATCH(tti_forward<float>(p, nshots, wavelet, wavelet_per_shot, rec_out, save),
+                    tti_forward<double>(p, nshots, wavelet, wavelet_per_shot, rec_out, save));
 }
 
 int mifwi_tti_adjoint(mifwi_plan *plan, int32_t nshots, const void *rec_in, void *srca_out)
 {
     PLAN_OR_FAIL(plan);
     return DISPATCH(tti_adjoint<float>(p, nshots, rec_in, srca_out), tti_adjoint<double>(p, nshots, rec_in, srca_out));
+}
+
+int mifwi_tti_born(mifwi_plan *plan, int32_t nshots, const void *wavelet, int32_t wavelet_per_shot, const void *dm,
+                   void *rec_out)
+{
+    PLAN_OR_FAIL(plan);
+    return DISPATCH(tti_born<float>(p, nshots, wavelet, wavelet_per_shot, dm, rec_out),
+                    tti_born<double>(p, nshots, wavelet, wavelet_per_shot, dm, rec_out));
+}
+
+int mifwi_tti_gradient(mifwi_plan *plan, int32_t nshots, const void *residual, void *grad, int32_t accumulate)
+{
+    PLAN_OR_FAIL(plan);
+    return DISPATCH(tti_gradient<float>(p, nshots, residual, grad, accumulate),
+                    tti_gradient<double>(p, nshots, residual, grad, accumulate));
 }
 
 int mifwi_read_wavefield(mifwi_plan *plan, int32_t which, int32_t shot, int32_t first, int32_t count, void *out)

@@ -125,6 +125,9 @@ struct Plan {
     // scratch [4][max_shots][field] (wA, wB, gzA, gzB)
     void *tti_par = nullptr, *tti_fwd = nullptr, *tti_adj = nullptr, *tti_tmp = nullptr;
     bool tti_fwd_valid = false, tti_adj_valid = false;
+    void *tti_save = nullptr;   // every level of both forward fields: [field][shot][nt] (tti_forward with save)
+    bool tti_save_valid = false;
+    int tti_save_shots = 0;
     // Injected terms of every time step, formed once before a time loop of the tiled kernels:
     // winj[shot][time][g] = (sum_e w_e vals[shot][time][point_e]) * dt^2 / m[cell], g in the order the
     // kernels walk the cells (tile-major slots in 2-D, cell_local order in 3-D)
@@ -268,6 +271,11 @@ template <typename T>
 int launch_tti_step(const Plan &p, const StepConsts<T> &k, const TtiParams<T> &q, int fwd, const TtiLevels<T> &lv,
                     T *wA, T *wB, T *gzA, T *gzB, int nshots, int &launches, const Step2DArgs *sparse2d);
 bool tti2d_available(const Plan &p);
+// grad[shot] += -( u0.dt2 * p + v0.dt2 * r ) at one time level (seismic/tti/operators.py:631); su/sv point at
+// level `time` of shot 0 of the saved fields, one level = level_stride elements
+template <typename T>
+int launch_tti_grad(const Plan &p, const StepConsts<T> &k, const T *su, const T *sv, long level_stride, long s_shot_stride,
+                    const T *pc, const T *rc, long a_shot_stride, T *grad, long g_shot_stride, int nshots);
 
 // ---- tiled 2-D fast path (kernels_tiled2d.hip) -------------------------------------------------
 // LDS row pitch (floats) of a staged tile.  ds_read_b128 serves a wave in four groups of 16 lanes

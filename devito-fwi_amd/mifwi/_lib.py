@@ -14,6 +14,7 @@ EXPORTED_SYMBOLS = (
     "mifwi_synchronize", "mifwi_set_model", "mifwi_set_geometry", "mifwi_forward", "mifwi_adjoint",
     "mifwi_gradient", "mifwi_l2_misfit_gradient", "mifwi_read_wavefield", "mifwi_write_wavefield",
     "mifwi_get_stats", "mifwi_born", "mifwi_tti_set_model", "mifwi_tti_forward", "mifwi_tti_adjoint",
+    "mifwi_tti_born", "mifwi_tti_gradient",
 )
 
 
@@ -81,7 +82,9 @@ def load_library():
     lib.mifwi_adjoint.argtypes = [vp, i32, vp, vp]
     lib.mifwi_born.argtypes = [vp, i32, vp, i32, vp, vp]
     lib.mifwi_tti_set_model.argtypes = [vp, vp, vp, vp, vp]
-    lib.mifwi_tti_forward.argtypes = [vp, i32, vp, i32, vp]
+    lib.mifwi_tti_forward.argtypes = [vp, i32, vp, i32, vp, i32]
+    lib.mifwi_tti_born.argtypes = [vp, i32, vp, i32, vp, vp]
+    lib.mifwi_tti_gradient.argtypes = [vp, i32, vp, vp, i32]
     lib.mifwi_tti_adjoint.argtypes = [vp, i32, vp, vp]
     lib.mifwi_gradient.argtypes = [vp, i32, vp, vp, i32, vp]
     lib.mifwi_l2_misfit_gradient.argtypes = [vp, i32, vp, i32, vp, vp, vp, vp, vp, vp]
@@ -237,12 +240,32 @@ class Plan(object):
             keep.append(ka)
         self._check(self._lib.mifwi_tti_set_model(self._h, *ptrs))
 
-    def tti_forward(self, wavelet, nshots=None, rec_out=None, wavelet_per_shot=False):
+    def tti_forward(self, wavelet, nshots=None, rec_out=None, wavelet_per_shot=False, save=False):
         nshots = nshots or self.nshots
         pw, kw = self._in(wavelet)
         pr, rec = self._out(rec_out, (nshots, self.nt, self.nrec))
-        self._check(self._lib.mifwi_tti_forward(self._h, nshots, pw, int(bool(wavelet_per_shot)), pr))
+        self._check(self._lib.mifwi_tti_forward(self._h, nshots, pw, int(bool(wavelet_per_shot)), pr,
+                                                int(bool(save))))
         return rec
+
+    def tti_born(self, wavelet, dm, nshots=None, rec_out=None, wavelet_per_shot=False):
+        """Linearised TTI data (nshots, nt, nrec) for the model perturbation dm (padded grid)."""
+        nshots = nshots or self.nshots
+        pw, kw = self._in(wavelet)
+        pd, kd = self._in(dm)
+        n = kd.numel() if _is_torch(kd) else kd.size
+        assert n == self.ngrid, "dm must cover the padded grid"
+        pr, rec = self._out(rec_out, (nshots, self.nt, self.nrec))
+        self._check(self._lib.mifwi_tti_born(self._h, nshots, pw, int(bool(wavelet_per_shot)), pd, pr))
+        return rec
+
+    def tti_gradient(self, residual, nshots=None, grad=None, accumulate=False):
+        """Per-shot TTI gradients (nshots, *shape) from the fields kept by tti_forward(save=True)."""
+        nshots = nshots or self.nshots
+        pi, ki = self._in(residual)
+        pg, grad = self._out(grad, (nshots,) + self.shape)
+        self._check(self._lib.mifwi_tti_gradient(self._h, nshots, pi, pg, int(bool(accumulate))))
+        return grad
 
     def tti_adjoint(self, rec_in, nshots=None, srca_out=None):
         nshots = nshots or self.nshots
@@ -292,7 +315,7 @@ class Plan(object):
         return dict(fval=fval, grad=grad, illum=il, residual=res, syn=syn)
 
     def read_wavefield(self, which=0, shot=0, first=0, count=None, out=None):
-        nlev = self.nt if which == 0 else 3
+        nlev = self.nt if which in (0, 7, 8) else 3
         count = nlev - first if count is None else count
         po, arr = self._out(out, (count,) + self.shape)
         self._check(self._lib.mifwi_read_wavefield(self._h, which, shot, first, count, po))

@@ -182,19 +182,36 @@ MIFWI_API int mifwi_l2_misfit_gradient(mifwi_plan *plan, int32_t nshots, const v
  * (wavesolver.py:153-159): arrays over the padded grid like vp (mifwi_set_model still supplies vp and
  * damp); phi may be NULL (2-D, or no azimuth).  space_order must be divisible by 4; 2-D or 3-D.
  * mifwi_tti_forward replaces op_fwd('centered').apply (wavesolver.py:160-166): the wavelet drives
- * both fields, rec_out (nshots, nt, nrec) samples u + v.  mifwi_tti_adjoint replaces op_adj().apply
- * (wavesolver.py:208-215): rec_in (nshots, nt, nrec) -> srca_out (nshots, nt, nsrc).  The last three
- * levels of (u, v) and (p, r) are readable through mifwi_read_wavefield which = 3, 4 and 5, 6. */
+ * both fields, rec_out (nshots, nt, nrec) samples u + v; save != 0 keeps every level of u and v on the
+ * device (TimeFunction(save=nt), wavesolver.py:127-137) for mifwi_tti_gradient -- 2 * nt fields per shot,
+ * no checkpointing on this path.  mifwi_tti_adjoint replaces op_adj().apply (wavesolver.py:208-215):
+ * rec_in (nshots, nt, nrec) -> srca_out (nshots, nt, nsrc).  The last three levels of (u, v) and (p, r)
+ * are readable through mifwi_read_wavefield which = 3, 4 and 5, 6, the saved levels of u and v through
+ * which = 7 and 8. */
 MIFWI_API int mifwi_tti_set_model(mifwi_plan *plan, const void *epsilon, const void *delta, const void *theta,
                         const void *phi);
 MIFWI_API int mifwi_tti_forward(mifwi_plan *plan, int32_t nshots, const void *wavelet, int32_t wavelet_per_shot,
-                      void *rec_out);
+                      void *rec_out, int32_t save);
 MIFWI_API int mifwi_tti_adjoint(mifwi_plan *plan, int32_t nshots, const void *rec_in, void *srca_out);
+
+/* Replaces: AnisotropicWaveSolver.jacobian -> op_jac().apply(dm, u0, v0, du, dv, src, rec, ...)
+ * (seismic/tti/wavesolver.py:219-280; seismic/tti/operators.py:529-587).  dm over the padded grid;
+ * rec_out (nshots, nt, nrec) receives the samples of du + dv. */
+MIFWI_API int mifwi_tti_born(mifwi_plan *plan, int32_t nshots, const void *wavelet, int32_t wavelet_per_shot,
+                   const void *dm, void *rec_out);
+
+/* Replaces: AnisotropicWaveSolver.jacobian_adjoint -> op_jacadj().apply(rec, dm, u0, v0, du, dv, ...)
+ * (seismic/tti/wavesolver.py:282-357; seismic/tti/operators.py:590-639), using the levels of u0 and v0
+ * kept on the device by the last mifwi_tti_forward(save = 1).  residual (nshots, nt, nrec);
+ * grad (nshots, *shape_pad) per shot, overwritten or (accumulate != 0) added to. */
+MIFWI_API int mifwi_tti_gradient(mifwi_plan *plan, int32_t nshots, const void *residual, void *grad,
+                       int32_t accumulate);
 
 /* Access to wavefield time levels of one shot, `u.data[first:first+count]` in the reference
  * (TimeFunction(save=nt), seismic/acoustic/wavesolver.py:104-106).  which = 0: saved forward
  * field (level index = time).  which = 1: the three rotating buffers of the last non-saving
- * forward run, which = 2: those of the last adjoint/gradient run (level index = time % 3). */
+ * forward run, which = 2: those of the last adjoint/gradient run (level index = time % 3).
+ * which = 3..8: TTI fields, see above. */
 MIFWI_API int mifwi_read_wavefield(mifwi_plan *plan, int32_t which, int32_t shot, int32_t first, int32_t count,
                          void *out);
 MIFWI_API int mifwi_write_wavefield(mifwi_plan *plan, int32_t shot, int32_t first, int32_t count, const void *in);

@@ -302,6 +302,41 @@ class TTIProblem(Problem):
         return srca
 
 
+    def born(self, src_coords, wavelet, rec_coords, dm, dt=None):
+        """seismic/tti/operators.py:529-587.  dm over the padded grid; returns the linearised data."""
+        dt = float(self.critical_dt if dt is None else dt)
+        sc, rc_ = self._coords(src_coords), self._coords(rec_coords)
+        w = np.ascontiguousarray(np.asarray(wavelet, dtype=self.dtype).reshape(-1, sc.shape[0]))
+        dm = np.ascontiguousarray(dm, dtype=self.dtype)
+        assert dm.shape == self.shape_pad
+        rec = np.zeros((w.shape[0], rc_.shape[0]), dtype=self.dtype)
+        fn = getattr(lib(), "oracle_tti_born_" + _sfx(self.dtype))
+        r = fn(self.ndim, _ia(self.shape_pad), _da(self.spacing), _da(self.origin_pad), self.space_order,
+               w.shape[0], ctypes.c_double(dt), _p(self.vp), _p(self.damp), _p(self.epsilon), _p(self.delta),
+               _p(self.theta), _p(self.phi), _p(dm), sc.shape[0], _p(sc), _p(w), rc_.shape[0], _p(rc_), _p(rec))
+        assert r == 0, r
+        return rec
+
+    def gradient(self, src_coords, wavelet, rec_coords, residual, dt=None, grad=None):
+        """seismic/tti/operators.py:590-639: forward modelling with both fields saved, then the adjoint
+        fields driven by `residual` (nt, nrec).  Accumulates into grad (padded grid) and returns it."""
+        dt = float(self.critical_dt if dt is None else dt)
+        sc, rc_ = self._coords(src_coords), self._coords(rec_coords)
+        w = np.ascontiguousarray(np.asarray(wavelet, dtype=self.dtype).reshape(-1, sc.shape[0]))
+        residual = np.ascontiguousarray(residual, dtype=self.dtype)
+        assert residual.shape == (w.shape[0], rc_.shape[0])
+        if grad is None:
+            grad = np.zeros(self.shape_pad, dtype=self.dtype)
+        assert grad.flags.c_contiguous and grad.dtype == self.dtype
+        fn = getattr(lib(), "oracle_tti_gradient_" + _sfx(self.dtype))
+        r = fn(self.ndim, _ia(self.shape_pad), _da(self.spacing), _da(self.origin_pad), self.space_order,
+               w.shape[0], ctypes.c_double(dt), _p(self.vp), _p(self.damp), _p(self.epsilon), _p(self.delta),
+               _p(self.theta), _p(self.phi), sc.shape[0], _p(sc), _p(w), rc_.shape[0], _p(rc_), _p(residual),
+               _p(grad))
+        assert r == 0, r
+        return grad
+
+
 # ----------------------------------------------------------------------------------------------
 # FWI glue (fwi.py of the reference)
 # ----------------------------------------------------------------------------------------------

@@ -82,6 +82,48 @@ def test_tti_tiled_kernel_matches_untiled_and_oracle(mifwi, shape, so):
         assert rel_l2(out["tiled"][1][s], prob.adjoint(src[s], rec[s], ref, dt=dt)) <= 1e-4
 
 
+@pytest.mark.parametrize("dtype,tol", [(np.float32, 5e-5), (np.float64, 1e-10)])
+@pytest.mark.parametrize("shape,so", [((41, 37), 8), ((60, 75), 16), ((17, 15, 19), 4)])
+def test_tti_jacobian_pair_parity(mifwi, shape, so, dtype, tol):
+    """mifwi_tti_born / mifwi_tti_forward(save) + mifwi_tti_gradient against the oracle's restatement
+    of seismic/tti/operators.py:529-639 (rel-L2; float32 gradients to 2e-4 like the acoustic ones)."""
+    prob, vp, src, rec, rng = tti_case(shape, so=so, nbl=10, dtype=dtype)
+    dt = float(prob.critical_dt)
+    nt = 90 if len(shape) == 2 else 40
+    w = orc.ricker(0.03, dt * np.arange(nt)).reshape(nt, 1).astype(dtype)
+    src, rec = src.astype(dtype), rec.astype(dtype)
+    dm = np.zeros(prob.shape_pad, dtype)
+    inner = tuple(slice(12, -12) for _ in shape)
+    dm[inner] = 0.02 * rng.standard_normal(dm[inner].shape)
+    plan = _plan(mifwi, prob, nt, dt, 1, rec.shape[0], src, rec)
+    jd = plan.tti_born(w, dm)[0]
+    ref = prob.born(src, w, rec, dm, dt=dt)
+    assert np.abs(ref).max() > 0 and rel_l2(jd, ref) <= tol
+    r = rng.standard_normal(ref.shape).astype(dtype)
+    d = plan.tti_forward(w, save=True)[0]
+    assert rel_l2(d, prob.forward(src, w, rec, dt=dt)) <= tol
+    u0 = plan.read_wavefield(7)
+    assert u0.shape == (nt,) + prob.shape_pad and np.abs(u0[nt - 1]).max() > 0 and not u0[:2].any()
+    g = plan.tti_gradient(r[None])[0]
+    gref = prob.gradient(src, w, rec, r, dt=dt)
+    assert np.abs(gref).max() > 0 and rel_l2(g, gref) <= 4 * tol
+    g2 = plan.tti_gradient(r[None], grad=g[None].copy(), accumulate=True)[0]
+    assert rel_l2(g2, 2 * gref) <= 4 * tol
+    if dtype == np.float64:      # <J dm, r> = <dm, J^T r> on the device
+        lhs, rhs = float(np.sum(jd * r)), float(np.sum(dm * g))
+        assert abs(lhs - rhs) <= 1e-10 * max(abs(lhs), abs(rhs))
+    plan.close()
+
+
+def test_tti_gradient_needs_saved_fields(mifwi):
+    prob, vp, src, rec, rng = tti_case((33, 35), so=8, dtype=np.float32)
+    nt, dt = 30, float(prob.critical_dt)
+    plan = _plan(mifwi, prob, nt, dt, 1, rec.shape[0], src.astype(np.float32), rec.astype(np.float32))
+    with pytest.raises(RuntimeError, match="save"):
+        plan.tti_gradient(np.zeros((1, nt, rec.shape[0]), np.float32))
+    plan.close()
+
+
 def test_tti_adjoint_pair_on_gpu(mifwi):
     prob, vp, src, rec, rng = tti_case((37, 41), so=8, dtype=np.float64)
     dt, nt = float(prob.critical_dt), 120

@@ -84,3 +84,39 @@ def test_tti_model_and_presets():
     assert not hasattr(m2, 'phi') or m2.phi is None or not hasattr(m2.phi, 'data')
     c = demo_model('constant-tti', shape=(20, 20), nbl=4, space_order=4)
     assert np.allclose(c.theta.data, .7) and np.allclose(c.delta.data, .2)
+
+
+@pytest.mark.parametrize("shape", [(37, 33), (15, 14, 17)])
+def test_tti_jacobian_pair_is_adjoint_and_linearises_forward(shape):
+    """seismic/tti/operators.py:529-639: <J dm, r> = <dm, J^T r> for the Born / gradient pair, and
+    J dm is the derivative of the forward map with respect to the squared slowness."""
+    prob, vp, src, rec, rng = tti_case(shape, nbl=6)
+    dt = float(prob.critical_dt)
+    nt = 90 if len(shape) == 2 else 40
+    w = orc.ricker(0.03, dt * np.arange(nt)).reshape(nt, 1)
+    dm = np.zeros(prob.shape_pad)
+    inner = tuple(slice(8, -8) for _ in shape)
+    dm[inner] = 0.02 * rng.standard_normal(dm[inner].shape)
+    jd = prob.born(src, w, rec, dm, dt=dt)
+    assert np.abs(jd).max() > 0
+    r = rng.standard_normal(jd.shape)
+    g = prob.gradient(src, w, rec, r, dt=dt)
+    lhs, rhs = float(np.sum(jd * r)), float(np.sum(dm * g))
+    assert abs(lhs - rhs) <= 1e-12 * max(abs(lhs), abs(rhs))
+    # gradient accumulates
+    g2 = prob.gradient(src, w, rec, r, dt=dt, grad=g.copy())
+    np.testing.assert_allclose(g2, 2 * g, rtol=1e-12, atol=0)
+    # finite difference of the forward map in m = 1/vp^2
+    d0 = prob.forward(src, w, rec, dt=dt)
+    errs = []
+    for h in (1e-2, 1e-3):
+        pert = copy_with_m(prob, prob.vp ** -2.0 + h * dm)
+        errs.append(np.linalg.norm((pert.forward(src, w, rec, dt=dt) - d0) / h - jd) / np.linalg.norm(jd))
+    assert errs[1] < 2e-3 and errs[1] < 0.2 * errs[0]       # first-order convergence
+
+
+def copy_with_m(prob, m):
+    import copy
+    q = copy.copy(prob)
+    q.vp = np.ascontiguousarray(m ** -0.5)
+    return q
