@@ -1332,8 +1332,7 @@ static int tti_set_model(Plan &p, const void *eps, const void *delta, const void
         }
         if ((rc = launch_tti_param<T>(p, k, src, par + (long)f * p.L.field, spec[f].mode, spec[f].halo))) return rc;
     }
-    p.tti_fwd_valid = p.tti_adj_valid = false;
-    return finish(p);
+    return finish(p);   // wavefields of earlier runs stay readable: they are not touched here
 }
 
 template <typename T>

@@ -18,7 +18,7 @@ class PlanEntry(object):
 
     def __init__(self, plan):
         self.plan = plan
-        self._tokens = {0: 0, 1: 0, 2: 0}
+        self._tokens = collections.defaultdict(int)   # wavefield storage id (mifwi_read_wavefield `which`) -> generation
         self._live = {}
         self.model_key = None
         self.geom_key = None
