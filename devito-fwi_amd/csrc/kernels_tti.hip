@@ -186,6 +186,8 @@ struct Tti2DArgs {
     int itp_npoint, itp_per_shot;
     float *vals_out;
     int time, nt;
+    float inv_dt2;
+    TtiExtra<float> x;   // MODE 1: gradient members, MODE 2: Born members
 };
 
 // LDS row pitch.  With TZ = 32 a wave covers rows ty and ty + 4 of the tile, so the two half-waves hit
@@ -196,7 +198,8 @@ __host__ __device__ constexpr int tti_pitch(int n, int tz)
     return tz == 32 ? (n + 7) / 16 * 16 + 8 : n;
 }
 
-template <int R, int TX, int TZ, bool FWD>
+// MODE 0: plain step, 1: adjoint step + gradient correlation, 2: forward step + Born source term
+template <int R, int TX, int TZ, bool FWD, int MODE>
 __global__ __launch_bounds__(256) void tti2d_kernel(Tti2DArgs a)
 {
     constexpr int P = R / 2, NT = 256;
@@ -364,27 +367,57 @@ __global__ __launch_bounds__(256) void tti2d_kernel(Tti2DArgs a)
         const float mz = pm[k], ed = pe[k] * a.dt;
         float un = (a.dt2 * H0 + 2.0f * mz * uc - mz * puo[k] + ed * uc) / (mz + ed);
         float vn = (a.dt2 * Hz + 2.0f * mz * vc - mz * pvo[k] + ed * vc) / (mz + ed);
+        const long i = a.off0 + (long)x * a.s1 + z;
+        if (MODE == 2) {
+            const long bi = (long)shot * a.x.b_shot_stride + i;
+            const float dmv = a.x.b_dm[i];
+            const float utt = (a.x.b_un[bi] - 2.0f * a.x.b_uc[bi] + a.x.b_uo[bi]) * a.inv_dt2;
+            const float vtt = (a.x.b_vn[bi] - 2.0f * a.x.b_vc[bi] + a.x.b_vo[bi]) * a.inv_dt2;
+            un += a.dt2 * (-dmv * utt) / (mz + ed);
+            vn += a.dt2 * (-dmv * vtt) / (mz + ed);
+        }
         if (ninj > 0) {
             const float add = acc[row * TZ + tz];
             un += add, vn += add;
         }
-        const long si = sbase + a.off0 + (long)x * a.s1 + z;
-        a.uout[si] = un;
-        a.vout[si] = vn;
+        a.uout[sbase + i] = un;
+        a.vout[sbase + i] = vn;
+        if (MODE == 1) {
+            // summed by parts over time: the second time difference is taken of the adjoint fields (all
+            // three levels are in registers) instead of the saved ones, so one saved level of each
+            // background field is read per step instead of three
+            const long gi = (long)shot * a.x.s_shot_stride + i;
+            const float ptt = (puo[k] - 2.0f * uc + un) * a.inv_dt2;
+            const float rtt = (pvo[k] - 2.0f * vc + vn) * a.inv_dt2;
+            float *g = a.x.grad + (long)shot * a.x.g_shot_stride + i;
+            *g += -(ptt * a.x.su[gi] + rtt * a.x.sv[gi]);
+        }
     }
+}
+
+template <int R, int TX, int TZ>
+static void launch_tti2d_rt(const Plan &p, const Tti2DArgs &a, int fwd, int nblocks)
+{
+    if (a.x.grad)
+        hipLaunchKernelGGL((tti2d_kernel<R, TX, TZ, false, 1>), dim3(nblocks), dim3(256), 0, p.stream, a);
+    else if (a.x.b_un)
+        hipLaunchKernelGGL((tti2d_kernel<R, TX, TZ, true, 2>), dim3(nblocks), dim3(256), 0, p.stream, a);
+    else if (fwd)
+        hipLaunchKernelGGL((tti2d_kernel<R, TX, TZ, true, 0>), dim3(nblocks), dim3(256), 0, p.stream, a);
+    else
+        hipLaunchKernelGGL((tti2d_kernel<R, TX, TZ, false, 0>), dim3(nblocks), dim3(256), 0, p.stream, a);
 }
 
 template <int R>
 static int launch_tti2d_r(const Plan &p, const Tti2DArgs &a, int fwd)
 {
     const int nblocks = a.ntx * a.ntz * a.nshots + (a.pt_idx ? ((a.itp_npoint + 255) / 256) * a.nshots : 0);
-    if (p.tile_tz == 64) {
-        if (fwd) hipLaunchKernelGGL((tti2d_kernel<R, 16, 64, true>), dim3(nblocks), dim3(256), 0, p.stream, a);
-        else hipLaunchKernelGGL((tti2d_kernel<R, 16, 64, false>), dim3(nblocks), dim3(256), 0, p.stream, a);
-    } else {
-        if (fwd) hipLaunchKernelGGL((tti2d_kernel<R, 32, 32, true>), dim3(nblocks), dim3(256), 0, p.stream, a);
-        else hipLaunchKernelGGL((tti2d_kernel<R, 32, 32, false>), dim3(nblocks), dim3(256), 0, p.stream, a);
+    if ((a.x.grad && fwd) || (a.x.b_un && !fwd)) {
+        set_error("TTI step: the gradient term belongs to the adjoint step, the Born term to the forward step");
+        return MIFWI_EINVAL;
     }
+    if (p.tile_tz == 64) launch_tti2d_rt<R, 16, 64>(p, a, fwd, nblocks);
+    else launch_tti2d_rt<R, 32, 32>(p, a, fwd, nblocks);
     MIFWI_HIP(hipGetLastError());
     return MIFWI_OK;
 }
@@ -395,9 +428,11 @@ bool tti2d_available(const Plan &p)
 }
 
 static int launch_tti2d(const Plan &p, const StepConsts<float> &k, const TtiParams<float> &q, int fwd,
-                        const TtiLevels<float> &lv, int nshots, const Step2DArgs &sp)
+                        const TtiLevels<float> &lv, int nshots, const Step2DArgs &sp, const TtiExtra<float> *extra)
 {
     Tti2DArgs a{};
+    if (extra) a.x = *extra;
+    a.inv_dt2 = k.inv_dt2;
     a.ucur = lv.ucur, a.uold = lv.uold, a.vcur = lv.vcur, a.vold = lv.vold, a.uout = lv.uout, a.vout = lv.vout;
     a.shot_stride = lv.shot_stride;
     a.m = (const float *)p.m, a.eta = (const float *)p.eta;
@@ -443,12 +478,13 @@ static int launch_tti_step_r(const Plan &p, const StepConsts<T> &k, const TtiPar
 // into wA, wB first.  Launch count is added to `launches`.
 template <typename T>
 int launch_tti_step(const Plan &p, const StepConsts<T> &k, const TtiParams<T> &q, int fwd, const TtiLevels<T> &lv,
-                    T *wA, T *wB, T *gzA, T *gzB, int nshots, int &launches, const Step2DArgs *sparse2d)
+                    T *wA, T *wB, T *gzA, T *gzB, int nshots, int &launches, const Step2DArgs *sparse2d,
+                    const TtiExtra<T> *extra)
 {
     if constexpr (std::is_same<T, float>::value) {
-        if (sparse2d) {   // tiled 2-D path: one launch for both fields and the sparse terms
+        if (sparse2d) {   // tiled 2-D path: one launch for both fields, the sparse terms and the extra term
             launches += 1;
-            return launch_tti2d(p, k, q, fwd, lv, nshots, *sparse2d);
+            return launch_tti2d(p, k, q, fwd, lv, nshots, *sparse2d, extra);
         }
     }
     const int e = q.p, e0 = p.L.ndim == 3 ? e : 0;
@@ -523,8 +559,10 @@ template int launch_tti_grad<double>(const Plan &, const StepConsts<double> &, c
                                      const double *, const double *, long, double *, long, int);
 
 template int launch_tti_step<float>(const Plan &, const StepConsts<float> &, const TtiParams<float> &, int,
-                                    const TtiLevels<float> &, float *, float *, float *, float *, int, int &, const Step2DArgs *);
+                                    const TtiLevels<float> &, float *, float *, float *, float *, int, int &, const Step2DArgs *,
+                                    const TtiExtra<float> *);
 template int launch_tti_step<double>(const Plan &, const StepConsts<double> &, const TtiParams<double> &, int,
-                                     const TtiLevels<double> &, double *, double *, double *, double *, int, int &, const Step2DArgs *);
+                                     const TtiLevels<double> &, double *, double *, double *, double *, int, int &, const Step2DArgs *,
+                                     const TtiExtra<double> *);
 
 }  // namespace mifwi

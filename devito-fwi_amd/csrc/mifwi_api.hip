@@ -1381,7 +1381,7 @@ struct TtiLoop {
         return MIFWI_OK;
     }
     int step(bool fwd, const TtiLevels<T> &lv, const SparseSet *inj, const T *vals_in, const SparseSet *itp,
-             T *vals_out, int time, int &launches)
+             T *vals_out, int time, int &launches, const TtiExtra<T> *extra = nullptr)
     {
         int r;
         if (tiled) {
@@ -1389,9 +1389,24 @@ struct TtiLoop {
             if (inj) set_inject(sa, *inj, p);
             if (itp) set_interp(sa, *itp, vals_out);
             sa.time = time, sa.nt = p.cfg.nt;
-            return launch_tti_step<T>(p, k, q, fwd, lv, wA, wB, gzA, gzB, nshots, launches, &sa);
+            return launch_tti_step<T>(p, k, q, fwd, lv, wA, wB, gzA, gzB, nshots, launches, &sa, extra);
         }
         if ((r = launch_tti_step<T>(p, k, q, fwd, lv, wA, wB, gzA, gzB, nshots, launches, nullptr))) return r;
+        if (extra && extra->b_un) {   // untiled path: the Born source terms are pointwise launches of their own
+            if ((r = launch_born_source<T>(p, k, extra->b_un, extra->b_uc, extra->b_uo, extra->b_shot_stride, extra->b_dm,
+                                           lv.uout, lv.shot_stride, nshots, 0)))
+                return r;
+            if ((r = launch_born_source<T>(p, k, extra->b_vn, extra->b_vc, extra->b_vo, extra->b_shot_stride, extra->b_dm,
+                                           lv.vout, lv.shot_stride, nshots, 0)))
+                return r;
+            launches += 2;
+        }
+        if (extra && extra->grad) {   // literal three-level form of the correlation
+            if ((r = launch_tti_grad<T>(p, k, extra->su, extra->sv, extra->level_stride, extra->s_shot_stride, lv.ucur,
+                                        lv.vcur, lv.shot_stride, extra->grad, extra->g_shot_stride, nshots)))
+                return r;
+            launches += 1;
+        }
         if (!inj && !itp) return MIFWI_OK;
         SparsePtrs<T> sq{};
         if (inj) sq.inj = inj, sq.field_inj = lv.uout, sq.field_inj2 = lv.vout, sq.vals_inj = vals_in;
@@ -1529,15 +1544,11 @@ static int tti_born(Plan &p, int nshots, const void *wavelet, int per_shot, cons
             const TtiLevels<T> b = tti_rot<T>(bu, bv, L.field, time, true), d = tti_rot<T>(dU, dV, L.field, time, true);
             int r;
             if ((r = loop.step(true, b, &p.src, (const T *)p.d_wavelet, nullptr, nullptr, time, launches))) return r;
-            if ((r = loop.step(true, d, nullptr, nullptr, &p.rec, (T *)p.d_rec, time, launches))) return r;
             // qu = -dm u0.dt2, qv = -dm v0.dt2 (u0.dt2 after the injection into u0[t+1])
-            if ((r = launch_born_source<T>(p, loop.k, b.uout, b.ucur, b.uold, stride, (const T *)p.d_dm, d.uout, stride,
-                                           nshots, 0)))
-                return r;
-            if ((r = launch_born_source<T>(p, loop.k, b.vout, b.vcur, b.vold, stride, (const T *)p.d_dm, d.vout, stride,
-                                           nshots, 0)))
-                return r;
-            launches += 2;
+            TtiExtra<T> x{};
+            x.b_un = b.uout, x.b_uc = b.ucur, x.b_uo = b.uold, x.b_vn = b.vout, x.b_vc = b.vcur, x.b_vo = b.vold;
+            x.b_shot_stride = stride, x.b_dm = (const T *)p.d_dm;
+            if ((r = loop.step(true, d, nullptr, nullptr, &p.rec, (T *)p.d_rec, time, launches, &x))) return r;
         }
         return MIFWI_OK;
     };
@@ -1578,11 +1589,10 @@ static int tti_gradient(Plan &p, int nshots, const void *residual, void *grad, i
         for (int time = nt - 2; time >= 1; --time) {
             const TtiLevels<T> a = tti_rot<T>(bp, br, L.field, time, false);
             int r;
-            if ((r = loop.step(false, a, &p.rec, (const T *)p.d_res, nullptr, nullptr, time, launches))) return r;
-            if ((r = launch_tti_grad<T>(p, loop.k, su + (long)time * L.field, sv + (long)time * L.field, L.field, sstride,
-                                        a.ucur, a.vcur, stride, (T *)p.d_grad, L.field, nshots)))
-                return r;
-            launches += 1;
+            TtiExtra<T> x{};
+            x.su = su + (long)time * L.field, x.sv = sv + (long)time * L.field, x.level_stride = L.field;
+            x.s_shot_stride = sstride, x.grad = (T *)p.d_grad, x.g_shot_stride = L.field;
+            if ((r = loop.step(false, a, &p.rec, (const T *)p.d_res, nullptr, nullptr, time, launches, &x))) return r;
         }
         return MIFWI_OK;
     };

@@ -264,12 +264,28 @@ struct TtiLevels {
 // (mode 1: 1+2x, 2: sqrt(1+2x), 3: cos, 4: sin); dense == null leaves the constant
 template <typename T>
 int launch_tti_param(const Plan &p, const StepConsts<T> &k, const T *dense, T *haloed, int mode, T halo_value);
+// Optional extra term of a TTI step.  Born (b_un != null): the stepped fields are the scattered ones and get
+// dt^2 * ( -dm * u0.dt2 ) / ( m + eta dt ) resp. the same with v0 (seismic/tti/operators.py:573-576);
+// b_* are the background levels t+1, t, t-1 of shot 0.  Gradient (grad != null): the stepped fields are the
+// adjoint ones and grad -= u0.dt2 * p + v0.dt2 * r (operators.py:631); su/sv point at level `time` of the
+// saved background fields of shot 0, consecutive levels level_stride apart.
+template <typename T>
+struct TtiExtra {
+    const T *b_un, *b_uc, *b_uo, *b_vn, *b_vc, *b_vo;
+    long b_shot_stride;
+    const T *b_dm;
+    const T *su, *sv;
+    long level_stride, s_shot_stride;
+    T *grad;
+    long g_shot_stride;
+};
 struct Step2DArgs;
 // sparse2d != null (float plans for which tti2d_available): the tiled 2-D kernel, which also adds the
 // injected terms and samples the receivers described by the injection/interpolation members of *sparse2d
 template <typename T>
 int launch_tti_step(const Plan &p, const StepConsts<T> &k, const TtiParams<T> &q, int fwd, const TtiLevels<T> &lv,
-                    T *wA, T *wB, T *gzA, T *gzB, int nshots, int &launches, const Step2DArgs *sparse2d);
+                    T *wA, T *wB, T *gzA, T *gzB, int nshots, int &launches, const Step2DArgs *sparse2d,
+                    const TtiExtra<T> *extra = nullptr);   // extra is honoured by the tiled kernel only
 bool tti2d_available(const Plan &p);
 // grad[shot] += -( u0.dt2 * p + v0.dt2 * r ) at one time level (seismic/tti/operators.py:631); su/sv point at
 // level `time` of shot 0 of the saved fields, one level = level_stride elements

@@ -25,12 +25,22 @@ for so in (8, 16):
         plan.tti_set_model(prob.epsilon, prob.delta, prob.theta, prob.phi)
         plan.set_geometry(src, rec)
         ng = float(np.prod(prob.shape_pad)) * nshots
-        bf = ba = 1e9
+        bf = ba = bs = bb = bg = 1e9
+        dm = np.zeros(prob.shape_pad, np.float32)
+        dm[60:-60, 60:-60] = 0.01
         for _ in range(3):
             r = plan.tti_forward(w)
             bf = min(bf, plan.stats()["fwd_ms"] / (nt - 2))
             plan.tti_adjoint(r)
             ba = min(ba, plan.stats()["bwd_ms"] / (nt - 2))
-        print("TTI 2-D %dx%d x %d shots so=%2d %-8s forward %.1f us/step (%.1f Gpts/s)  adjoint %.1f us/step" %
-              (prob.shape_pad + (nshots, so, name, bf * 1e3, ng / bf / 1e6, ba * 1e3)), flush=True)
+            plan.tti_forward(w, save=True)
+            bs = min(bs, plan.stats()["fwd_ms"] / (nt - 2))
+            plan.tti_gradient(r)
+            bg = min(bg, plan.stats()["bwd_ms"] / (nt - 2))
+            plan.tti_born(w, dm)
+            bb = min(bb, plan.stats()["fwd_ms"] / (nt - 2))
+        print("TTI 2-D %dx%d x %d shots so=%2d %-8s forward %.1f us/step (%.1f Gpts/s)  adjoint %.1f  forward(save) %.1f  "
+              "gradient %.1f  born %.1f us/step" %
+              (prob.shape_pad + (nshots, so, name, bf * 1e3, ng / bf / 1e6, ba * 1e3, bs * 1e3, bg * 1e3, bb * 1e3)),
+              flush=True)
         plan.close()
