@@ -7,8 +7,12 @@ linear in the wavelet, and the checkpointed gradient equals the fully saved one 
 Sizes: the 3-D north-star grid 512^3 + 2*40 = 592^3 at space order 16 (and 8), and Marmousi-II
 (420 x 220 padded, nt = 1501, 8 shots, space order 16).
 Tolerance of the float32 adjoint test: 2e-5 relative in 3-D (measured 7.7e-6 at order 16, 1.4e-6 at
-order 8), 1e-5 for Marmousi-II (the float64 pair agrees to 1e-15 on small grids; float32 accumulates
-rounding over the time loop and the random test vectors cancel heavily in the inner products).
+order 8).  For Marmousi-II (full nt, white-noise test vectors) the inner products cancel to ~1e-5 of
+the product of the norms, so the difference is bounded against that product instead:
+|<a,b> - <c,d>| <= tol * max(|a||b|, |c||d|), tol = 5e-8 for the acoustic pair (measured 1e-9 .. 9e-9)
+and 3e-6 for the TTI propagator and Jacobian pairs (measured 3e-7 .. 8e-7, tiled and untiled kernels
+alike: Gxx = laplace - Gzz subtracts two large float32 terms, and white noise is the worst case for
+it).  In float64 the same full-size TTI pair agrees to 2e-15.
 """
 import os
 
@@ -28,6 +32,15 @@ def mifwi():
 
 def _dot(a, b):
     return float(np.sum(a.astype(np.float64) * b.astype(np.float64)))
+
+
+def _pair_ok(a, b, c, d, tol):
+    """<a, b> against <c, d>, bounded relative to the Cauchy-Schwarz scale of the two products."""
+    n = lambda x: float(np.linalg.norm(x.astype(np.float64).ravel()))
+    lhs, rhs = _dot(a, b), _dot(c, d)
+    scale = max(n(a) * n(b), n(c) * n(d))
+    print("<a,b> = %.9e  <c,d> = %.9e  diff/scale = %.2e" % (lhs, rhs, abs(lhs - rhs) / scale))
+    return abs(lhs - rhs) <= tol * scale and abs(lhs) > 1e-12 * scale
 
 
 @pytest.mark.parametrize("so", [16, 8])
@@ -72,7 +85,8 @@ def test_marmousi2_full_adjoint_pair_and_checkpoint_identity(mifwi):
     shape, nbl, so = (340, 140), 40, 16
     data = os.path.join(ROOT, "tests", "golden", "model_data", "SMARM2")
     vp = np.fromfile(os.path.join(data, "vp.smooth_20"), dtype=np.float32).reshape(shape) / 1000
-    model = Model(origin=(0, 0), spacing=(25., 25.), shape=shape, space_order=so, vp=vp, nbl=nbl, dt=3.0)
+    model = Model(origin=(0, 0), spacing=(25., 25.), shape=shape, space_order=so, vp=vp, nbl=nbl, dt=3.0,
+                  bcs="damp")
     dt, nt, nshots, nrec = 3.0, 1501, 8, 340
     src = np.empty((nshots, 1, 2), dtype=np.float32)
     src[:, 0, 0] = np.linspace(0, model.domain_size[0], nshots)
@@ -93,10 +107,51 @@ def test_marmousi2_full_adjoint_pair_and_checkpoint_identity(mifwi):
             fs = plan.forward(s, wavelet_per_shot=True)
             ftr = plan.adjoint(r)
             for k in range(nshots):
-                lhs, rhs = _dot(fs[k], r[k]), _dot(s[k], ftr[k])
-                assert abs(lhs - rhs) <= 1e-5 * max(abs(lhs), abs(rhs)), (k, lhs, rhs)
+                assert _pair_ok(fs[k], r[k], s[k], ftr[k], 5e-8), k
         plan.forward(s, wavelet_per_shot=True, save=True)
         out[name] = plan.gradient(r, want_illum=True)
         plan.close()
     assert np.array_equal(out["full"][0], out["ckpt"][0])
     assert np.array_equal(out["full"][1], out["ckpt"][1])
+
+
+def test_marmousi2_tti_full_size_pairs(mifwi):
+    """2-D TTI on Marmousi-II at space order 8, two shots (the per-GPU share of 16 shots on 8 GPUs), full
+    nt: <F s, r> = <s, F^T r> and <J dm, r> = <dm, J^T r> (seismic/tti/operators.py:430-639) in float32.
+    The reference ships no Marmousi-II anisotropy rasters: epsilon, delta, theta follow the recipe of its
+    `layers-tti` preset (preset_models.py:212-214) applied to vp, scaled to the velocity range."""
+    from seismic import Model
+    shape, nbl, so = (340, 140), 40, 8
+    data = os.path.join(ROOT, "tests", "golden", "model_data", "SMARM2")
+    vp = np.fromfile(os.path.join(data, "vp.smooth_20"), dtype=np.float32).reshape(shape) / 1000
+    eps, delta, theta = 0.3 * (vp - 1.5) / 3.2, 0.2 * (vp - 1.5) / 3.2, 0.5 * (vp - 1.5) / 3.2
+    model = Model(origin=(0, 0), spacing=(25., 25.), shape=shape, space_order=so, vp=vp, nbl=nbl,
+                  epsilon=eps, delta=delta, theta=theta, bcs="damp")
+    dt, nt, nshots, nrec = float(model.critical_dt), 1501, 2, 340
+    src = np.empty((nshots, 1, 2), dtype=np.float32)
+    src[:, 0, 0] = np.array([0.3, 0.7], dtype=np.float32) * model.domain_size[0]
+    src[:, 0, 1] = 50.0
+    rec = np.empty((nrec, 2), dtype=np.float32)
+    rec[:, 0] = np.linspace(25.0, model.domain_size[0] - 25.0, nrec)
+    rec[:, 1] = 50.0
+    rng = np.random.default_rng(13)
+    s = rng.standard_normal((nshots, nt, 1)).astype(np.float32)
+    r = rng.standard_normal((nshots, nt, nrec)).astype(np.float32)
+    plan = mifwi.Plan(model.grid.shape, model.spacing, model.grid.origin, so, nt, dt, 1, nrec, max_shots=nshots)
+    plan.set_model(model.vp.data, model.damp.data)
+    plan.tti_set_model(model.epsilon.data, model.delta.data, model.theta.data)
+    plan.set_geometry(src, rec)
+    fs = plan.tti_forward(s, wavelet_per_shot=True)
+    ftr = plan.tti_adjoint(r)
+    assert np.isfinite(fs).all() and np.abs(fs).max() > 0
+    for k in range(nshots):
+        assert _pair_ok(fs[k], r[k], s[k], ftr[k], 3e-6), k
+    dm = np.zeros(model.grid.shape, np.float32)
+    dm[60:-60, 60:-60] = 0.01 * rng.standard_normal((300, 100)).astype(np.float32)
+    jd = plan.tti_born(s, dm, wavelet_per_shot=True)
+    plan.tti_forward(s, wavelet_per_shot=True, save=True)
+    g = plan.tti_gradient(r)
+    assert np.abs(jd).max() > 0
+    for k in range(nshots):
+        assert _pair_ok(jd[k], r[k], dm, g[k], 3e-6), k
+    plan.close()
