@@ -70,6 +70,34 @@ __device__ inline void stv_stream(char *base, unsigned off, const float (&d)[V])
     for (int i = 0; i < V; ++i) v[i] = d[i];
     __builtin_nontemporal_store(v, reinterpret_cast<typename VecT<V>::type *>(base + off));
 }
+// V consecutive points of a half-precision saved level; `off` is their byte offset in a float field
+typedef unsigned vu2 __attribute__((ext_vector_type(2)));
+template <int V>
+__device__ inline void ldv_half_stream(const char *base, unsigned off, float inv_scale, float (&d)[V])
+{
+    if (V == 4) {
+        const vu2 v = __builtin_nontemporal_load(reinterpret_cast<const vu2 *>(base + (off >> 1)));
+        unpack_half2(v.x, d[0], d[1]);
+        unpack_half2(v.y, d[V - 2], d[V - 1]);
+    } else {
+        const unsigned v = __builtin_nontemporal_load(reinterpret_cast<const unsigned *>(base + (off >> 1)));
+        unpack_half2(v, d[0], d[1]);
+    }
+#pragma unroll
+    for (int i = 0; i < V; ++i) d[i] *= inv_scale;
+}
+template <int V>
+__device__ inline void stv_half_stream(char *base, unsigned off, const float (&d)[V], float scale)
+{
+    if (V == 4) {
+        vu2 v;
+        v.x = pack_half2(d[0] * scale, d[1] * scale);
+        v.y = pack_half2(d[V - 2] * scale, d[V - 1] * scale);
+        __builtin_nontemporal_store(v, reinterpret_cast<vu2 *>(base + (off >> 1)));
+    } else {
+        __builtin_nontemporal_store(pack_half2(d[0] * scale, d[1] * scale), reinterpret_cast<unsigned *>(base + (off >> 1)));
+    }
+}
 template <int V>
 __device__ inline void lds_ldv(const float *p, float (&d)[V])
 {
@@ -94,9 +122,10 @@ __device__ inline void lds_stv(float *p, const float (&d)[V])
 #ifndef MIFWI_3D_GRAD_WAVES
 #define MIFWI_3D_GRAD_WAVES 2
 #endif
-// MODE 0: plain propagation, 1: gradient, 2: scattered field of Born modelling.
+// MODE 0: plain propagation, 1: gradient, 2: scattered field of Born modelling, 3: plain propagation that
+// also streams a half-precision copy of the new level into the saved array.
 template <int R, int TY, int TZ, int V, int MODE, bool ISO>
-__global__ __launch_bounds__(TY *TZ / V, (MODE != 0 ? MIFWI_3D_GRAD_WAVES : 3) * (TY * TZ / V) / 256) void step3d_kernel(Step3DArgs a)
+__global__ __launch_bounds__(TY *TZ / V, (MODE == 1 || MODE == 2 ? MIFWI_3D_GRAD_WAVES : 3) * (TY * TZ / V) / 256) void step3d_kernel(Step3DArgs a)
 {
     constexpr bool GRAD = (MODE == 1), BORN = (MODE == 2);
     constexpr int NT = TY * TZ / V;                     // threads per block
@@ -282,8 +311,14 @@ __global__ __launch_bounds__(TY *TZ / V, (MODE != 0 ? MIFWI_3D_GRAD_WAVES : 3) *
             illumb = a.illum ? reinterpret_cast<char *>(a.illum + (long)shot * a.g_shot_stride) + (long)x * sb : nullptr;
             if (live) {
                 const long us = (long)shot * a.u_shot_stride * 4 + (long)x * sb;
-                ldv_stream<V>(reinterpret_cast<const char *>(a.uc) + us, col, u0);
-                if (a.first && illumb) ldv_stream<V>(reinterpret_cast<const char *>(a.up) + us, col, up);
+                if (a.save_scale) {   // half-precision saved levels (uniform branch)
+                    const float inv = 1.0f / a.save_scale[shot];
+                    ldv_half_stream<V>(reinterpret_cast<const char *>(a.uc) + (us >> 1), col, inv, u0);
+                    if (a.first && illumb) ldv_half_stream<V>(reinterpret_cast<const char *>(a.up) + (us >> 1), col, inv, up);
+                } else {
+                    ldv_stream<V>(reinterpret_cast<const char *>(a.uc) + us, col, u0);
+                    if (a.first && illumb) ldv_stream<V>(reinterpret_cast<const char *>(a.up) + us, col, up);
+                }
                 ldv_stream<V>(gradb, col, g);
                 if (illumb) ldv_stream<V>(illumb, col, il);
             }
@@ -357,6 +392,18 @@ __global__ __launch_bounds__(TY *TZ / V, (MODE != 0 ? MIFWI_3D_GRAD_WAVES : 3) *
                 for (int i = 0; i < V; ++i)
                     if (z + i < a.n2) po[i] = res[i];
             }
+            if (MODE == 3) {
+                // half-precision copy of the new level into the saved array
+                const float sc = a.save_scale[shot];
+                char *cb = reinterpret_cast<char *>(a.copy16) + (((long)shot * a.copy_shot_stride * 4 + (long)x * sb) >> 1);
+                if (full) {
+                    stv_half_stream<V>(cb, col, res, sc);
+                } else {
+                    __half *ch = reinterpret_cast<__half *>(cb + (col >> 1));
+                    for (int i = 0; i < V; ++i)
+                        if (z + i < a.n2) ch[i] = __float2half_rn(fminf(fmaxf(res[i] * sc, -65504.0f), 65504.0f));
+                }
+            }
             if (a.fs && z <= R) {
                 // free surface: antisymmetric mirror of rows 1..R into the z halo (see kernels_tiled2d.hip)
                 float *po = reinterpret_cast<float *>(out + (long)x * sb + col);
@@ -429,6 +476,8 @@ static int launch_r3v(const Plan &p, const Step3DArgs &a, hipStream_t stream)
         hipLaunchKernelGGL((step3d_kernel<R, 16, 64, 4, 2, ISO>), dim3((a.nwork + 7) / 8 * 8 +
                                (a.pt_idx ? (((a.itp_npoint + 255) / 256) * a.nshots + 7) / 8 * 8 : 0)),
                            dim3(256), 0, stream, a);
+    else if (a.copy16)
+        hipLaunchKernelGGL((step3d_kernel<R, 16, 64, V, 3, ISO>), dim3(nblocks), dim3(NT), 0, stream, a);
     else
         hipLaunchKernelGGL((step3d_kernel<R, 16, 64, V, 0, ISO>), dim3(nblocks), dim3(NT), 0, stream, a);
     MIFWI_HIP(hipGetLastError());

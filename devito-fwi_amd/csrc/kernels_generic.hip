@@ -519,4 +519,50 @@ template int launch_l2_misfit<float>(const Plan &, const float *, const float *,
 template int launch_l2_misfit<double>(const Plan &, const double *, const double *, double *, long, int, double *,
                                       double *);
 
+// ------------------------------------------------------------------------------------------
+// Half-precision saved levels.  Scale of one shot: 64 / max |injected source term| over the whole run
+// (terms are dt^2 * wavelet * weight / m, the per-step increments of the field at the source cells).
+// The field's peak is about (samples per wavelet period) / 4 such increments in 2-D (12 on Marmousi-II)
+// and less in 3-D, so it lands near 8e2 of the half format's 65504 -- a factor ~80 of headroom, values
+// beyond it saturate -- with 11 significant bits down to 8e-8 of the peak (the error is the mantissa
+// rounding either way: scales of 16 and 256 gave the same gradients to three digits).  A silent shot gets scale 1.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void save_scale_kernel(const float *winj, long per_shot, float *scale)
+{
+    __shared__ float red[256];
+    const int shot = blockIdx.x;
+    float m = 0.f;
+    if (winj)
+        for (long i = threadIdx.x; i < per_shot; i += 256) m = fmaxf(m, fabsf(winj[(long)shot * per_shot + i]));
+    red[threadIdx.x] = m;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + s]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) scale[shot] = (red[0] > 0.f && isfinite(red[0])) ? 64.0f / red[0] : 1.0f;
+}
+
+int launch_save_scale(const Plan &p, const float *winj, long per_shot, int nshots, float *scale)
+{
+    hipLaunchKernelGGL(save_scale_kernel, dim3(nshots), dim3(256), 0, p.stream, winj, per_shot, scale);
+    MIFWI_HIP(hipGetLastError());
+    return MIFWI_OK;
+}
+
+__global__ __launch_bounds__(256) void half_to_float_kernel(const __half *src, float *dst, long n, const float *scale,
+                                                            int shot)
+{
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) dst[i] = __half2float(src[i]) / scale[shot];
+}
+
+int launch_half_to_float(const Plan &p, const void *src, float *dst, long n, const float *scale, int shot)
+{
+    hipLaunchKernelGGL(half_to_float_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, p.stream,
+                       (const __half *)src, dst, n, scale, shot);
+    MIFWI_HIP(hipGetLastError());
+    return MIFWI_OK;
+}
+
 }  // namespace mifwi

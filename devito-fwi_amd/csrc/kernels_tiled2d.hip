@@ -85,6 +85,25 @@ __device__ inline float4 ld4_saved(const float *p)
 #endif
 }
 
+// Four consecutive points of a half-precision saved level: `off` is the byte offset the same points have
+// in a float field, so the halves sit at off / 2 (8-byte aligned).
+typedef unsigned vuint2_2d __attribute__((ext_vector_type(2)));
+__device__ inline float4 ld4_half_stream_at(const char *base, unsigned off, float inv_scale)
+{
+    const vuint2_2d v = __builtin_nontemporal_load(reinterpret_cast<const vuint2_2d *>(base + (off >> 1)));
+    float4 r;
+    unpack_half2(v.x, r.x, r.y);
+    unpack_half2(v.y, r.z, r.w);
+    return make_float4(r.x * inv_scale, r.y * inv_scale, r.z * inv_scale, r.w * inv_scale);
+}
+__device__ inline void st4_half_stream_at(char *base, unsigned off, float4 v, float scale)
+{
+    vuint2_2d t;
+    t.x = pack_half2(v.x * scale, v.y * scale);
+    t.y = pack_half2(v.z * scale, v.w * scale);
+    __builtin_nontemporal_store(t, reinterpret_cast<vuint2_2d *>(base + (off >> 1)));
+}
+
 // MODE 0: plain propagation, 1: gradient, 2: scattered field of Born modelling.
 template <int R, int TX, int TZ, int MODE>
 // Register budget of the gradient variant: 128 VGPRs, i.e. four blocks per CU (unconstrained it takes
@@ -159,8 +178,16 @@ __global__ __launch_bounds__(TX *TZ / 4, MODE == 1 ? 4 : 1) void step2d_kernel(S
         e4 = ld4_at(reinterpret_cast<const char *>(a.eta), pb);
         o4 = ld4_at(oldb, pb);
         if (GRAD) {
-            u04 = ld4_stream_at(reinterpret_cast<const char *>(a.uc + (long)shot * a.u_shot_stride), pb);
-            if (a.first && a.illum) up4 = ld4_at(reinterpret_cast<const char *>(a.up + (long)shot * a.u_shot_stride), pb);
+            if (a.save_scale) {   // half-precision saved levels (block-uniform branch)
+                const float inv = 1.0f / a.save_scale[shot];
+                const long hs = (long)shot * a.u_shot_stride * 2;
+                u04 = ld4_half_stream_at(reinterpret_cast<const char *>(a.uc) + hs, pb, inv);
+                if (a.first && a.illum) up4 = ld4_half_stream_at(reinterpret_cast<const char *>(a.up) + hs, pb, inv);
+            } else {
+                u04 = ld4_stream_at(reinterpret_cast<const char *>(a.uc + (long)shot * a.u_shot_stride), pb);
+                if (a.first && a.illum)
+                    up4 = ld4_at(reinterpret_cast<const char *>(a.up + (long)shot * a.u_shot_stride), pb);
+            }
             gv = ld4_at(reinterpret_cast<const char *>(a.grad + (long)shot * a.g_shot_stride), pb);
             if (a.illum) iv = ld4_at(reinterpret_cast<const char *>(a.illum + (long)shot * a.g_shot_stride), pb);
         }
@@ -248,7 +275,18 @@ __global__ __launch_bounds__(TX *TZ / 4, MODE == 1 ? 4 : 1) void step2d_kernel(S
             for (int i = 0; i < 4; ++i)
                 if (z + i < a.n2) a.out[ps + i] = res[i];
         }
-        if (a.copy) {
+        if (a.copy && a.save_scale) {
+            // half-precision saved level
+            const float sc = a.save_scale[shot];
+            char *cb = reinterpret_cast<char *>(a.copy) + (long)shot * a.copy_shot_stride * 2;
+            if (full) {
+                st4_half_stream_at(cb, pb, make_float4(res[0], res[1], res[2], res[3]), sc);
+            } else {
+                __half *ch = reinterpret_cast<__half *>(cb) + p;
+                for (int i = 0; i < 4; ++i)
+                    if (z + i < a.n2) ch[i] = __float2half_rn(fminf(fmaxf(res[i] * sc, -65504.0f), 65504.0f));
+            }
+        } else if (a.copy) {
             // the saved forward level is a write-only stream here: the time loop itself runs on the
             // three rotating levels, which stay cache resident
             float *cp = a.copy + (long)shot * a.copy_shot_stride + p;

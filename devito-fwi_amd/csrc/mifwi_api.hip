@@ -169,6 +169,7 @@ static void destroy(Plan *p)
     dev_free(p->tti_adj);
     dev_free(p->tti_tmp);
     dev_free(p->tti_save);
+    dev_free(p->d_save_scale);
     dev_free(p->d_t4);
     dev_free(p->d_w2);
     dev_free(p->d_dense);
@@ -795,6 +796,7 @@ static int forward_step(Plan &p, const LoopCtx<T> &c, const T *cur, const T *old
         if (interp) set_interp(a, p.rec, p.d_rec);
         a.cur = (const float *)cur, a.old = (const float *)old, a.out = (float *)out, a.time = time;
         a.copy = (float *)copy, a.copy_shot_stride = copy_stride;
+        if (copy && p.save_f16) a.save_scale = (const float *)p.d_save_scale;
         if (born) {
             a.b_un = (const float *)born->un, a.b_uc = (const float *)born->uc, a.b_uo = (const float *)born->uo;
             a.b_dm = (const float *)born->dm, a.b_shot_stride = born->shot_stride;
@@ -809,6 +811,10 @@ static int forward_step(Plan &p, const LoopCtx<T> &c, const T *cur, const T *old
         if (inject) set_inject3(a, p.src, p);
         if (interp) set_interp3(a, p.rec, p.d_rec);
         a.cur = (const float *)cur, a.old = (const float *)old, a.out = (float *)out, a.time = time;
+        if (copy) {
+            if (!p.save_f16) return fail(MIFWI_EINVAL, "internal: the 3-D kernel copies half-precision levels only");
+            a.copy16 = copy, a.copy_shot_stride = copy_stride, a.save_scale = (const float *)p.d_save_scale;
+        }
         if (born) {
             a.b_un = (const float *)born->un, a.b_uc = (const float *)born->uc, a.b_uo = (const float *)born->uo;
             a.b_dm = (const float *)born->dm, a.b_shot_stride = born->shot_stride;
@@ -871,6 +877,7 @@ static int backward_step(Plan &p, const LoopCtx<T> &c, const T *cur, const T *ol
         if (with_grad) {
             a.um = (const float *)um, a.uc = (const float *)u0, a.up = (const float *)up;
             a.u_shot_stride = u_stride;
+            if (p.save_f16) a.save_scale = (const float *)p.d_save_scale;
             a.grad = (float *)p.d_grad;
             a.illum = with_illum ? (float *)p.d_illum : nullptr;
             a.g_shot_stride = p.L.field;
@@ -889,6 +896,7 @@ static int backward_step(Plan &p, const LoopCtx<T> &c, const T *cur, const T *ol
         if (with_grad) {
             a.um = (const float *)um, a.uc = (const float *)u0, a.up = (const float *)up;
             a.u_shot_stride = u_stride;
+            if (p.save_f16) a.save_scale = (const float *)p.d_save_scale;
             a.grad = (float *)p.d_grad;
             a.illum = with_illum ? (float *)p.d_illum : nullptr;
             a.g_shot_stride = p.L.field;
@@ -1004,11 +1012,19 @@ static int prepare_save(Plan &p)
     size_t free_b = 0, total_b = 0;
     MIFWI_HIP(hipMemGetInfo(&free_b, &total_b));
     const bool force = (p.cfg.flags & MIFWI_FLAG_CHECKPOINT) != 0;
+    // half-precision levels: float32 plans on the tiled kernels only
+    const bool want_f16 = (p.cfg.flags & MIFWI_FLAG_SAVE_F16) && std::is_same<T, float>::value && p.kind != 0;
+    const size_t slevel = want_f16 ? level / 2 : level;
     int rc;
-    if (!force && (double)level * nt <= 0.85 * (double)free_b) {
+    if (!force && (double)slevel * nt <= 0.85 * (double)free_b) {
         p.ck_K = 0;
-        return dev_alloc(p, &p.saved, level * nt, true);
+        p.save_f16 = want_f16;
+        if (want_f16 && !p.d_save_scale &&
+            (rc = dev_alloc(p, &p.d_save_scale, (size_t)p.cfg.max_shots * sizeof(float), true)))
+            return rc;
+        return dev_alloc(p, &p.saved, slevel * nt, true);
     }
+    p.save_f16 = false;   // checkpoints restart the propagation and stay float32
     const int nsteps = nt - 2;
     p.ck_K = std::max(2, (int)std::ceil(std::sqrt(2.0 * nsteps)));
     p.ck_nseg = (nsteps + p.ck_K - 1) / p.ck_K;
@@ -1032,7 +1048,9 @@ static int run_forward(Plan &p, int nshots, int save)
     // Tiled 2-D kernel: the loop runs on the three rotating levels and streams a copy of every new
     // level into the saved array; measured 1.2-1.4 us per step faster than stepping through the
     // saved array itself, whose freshly written levels are not cache resident when read back.
-    const bool copy_save = full_save && p.kind == 1;
+    // Half-precision levels are always written as a copy (2-D and 3-D): stepping needs float32 levels.
+    const bool copy_save = full_save && (p.kind == 1 || p.save_f16);
+    const size_t es = p.save_f16 ? 2 : sizeof(T);   // bytes per saved element
     T *base;
     long shot_stride;
     if (full_save && !copy_save) {
@@ -1047,11 +1065,17 @@ static int run_forward(Plan &p, int nshots, int save)
         MIFWI_HIP(hipMemsetAsync(base, 0, (size_t)nshots * shot_stride * sizeof(T), p.stream));
         p.rot_u_valid = false;
         if (copy_save)   // u[0] = u[1] = 0
-            MIFWI_HIP(hipMemsetAsync(p.saved, 0, 2 * (size_t)p.cfg.max_shots * L.field * sizeof(T), p.stream));
+            MIFWI_HIP(hipMemsetAsync(p.saved, 0, 2 * (size_t)p.cfg.max_shots * L.field * es, p.stream));
     }
     if (save) p.saved_valid = false;
     MIFWI_HIP(hipMemsetAsync(p.d_rec, 0, (size_t)nshots * nt * p.cfg.nrec * sizeof(T), p.stream));
     if ((rc = prepare_injection<T>(p, p.src, p.d_wavelet, nshots))) return rc;
+    if (copy_save && p.save_f16) {
+        const bool have = p.src.npoint > 0 && p.src.max_count > 0;
+        if ((rc = launch_save_scale(p, have ? (const float *)p.d_winj[0] : nullptr, (long)nt * p.src.kmax, nshots,
+                                    (float *)p.d_save_scale)))
+            return rc;
+    }
     const LoopCtx<T> ctx = make_ctx<T>(p, nshots, false);
     const long sv_lstride = (long)p.cfg.max_shots * L.field;
     const bool in_saved = full_save && !copy_save;
@@ -1068,7 +1092,7 @@ static int run_forward(Plan &p, int nshots, int save)
                 if ((r = copy_levels<T>(p, dst, cstride, lvl(time - 1), shot_stride, 1, nshots))) return r;
                 if ((r = copy_levels<T>(p, dst + L.field, cstride, lvl(time), shot_stride, 1, nshots))) return r;
             }
-            T *copy = copy_save ? (T *)p.saved + (long)(time + 1) * sv_lstride : nullptr;
+            T *copy = copy_save ? (T *)((char *)p.saved + (size_t)(time + 1) * sv_lstride * es) : nullptr;
             int r = forward_step<T>(p, ctx, lvl(time), lvl(time - 1), lvl(time + 1), shot_stride, time, true, launches,
                                     true, copy, L.field);
             if (r) return r;
@@ -1122,13 +1146,16 @@ static int run_backward(Plan &p, int nshots, bool with_grad, bool with_illum)
     auto enqueue = [&](int &launches) -> int {
         int r;
         if (!ckpt) {
-            const T *sv = (const T *)p.saved;
+            // saved levels: float, or half precision (then the kernels take the pointers as raw addresses)
+            const char *sv = (const char *)p.saved;
+            const size_t es = p.save_f16 ? 2 : sizeof(T);
             const long sv_lstride = (long)p.cfg.max_shots * L.field, sv_stride = L.field;
+            auto saved_level = [&](int t) { return (const T *)(sv + (size_t)t * sv_lstride * es); };
             for (int time = nt - 2; time >= 1; --time) {
-                const T *u0 = with_grad ? sv + (long)time * sv_lstride : nullptr;
+                const T *u0 = with_grad ? saved_level(time) : nullptr;
                 if ((r = backward_step<T>(p, ctx, lvl(time), lvl(time + 1), lvl(time - 1), shot_stride, time,
-                                          u0 ? u0 - sv_lstride : nullptr, u0, u0 ? u0 + sv_lstride : nullptr, sv_stride,
-                                          with_illum, time == nt - 2, launches)))
+                                          u0 ? saved_level(time - 1) : nullptr, u0, u0 ? saved_level(time + 1) : nullptr,
+                                          sv_stride, with_illum, time == nt - 2, launches)))
                     return r;
             }
             return MIFWI_OK;
@@ -1606,6 +1633,26 @@ static int tti_gradient(Plan &p, int nshots, const void *residual, void *grad, i
     return finish(p);
 }
 
+// levels first .. first+count-1 of one shot of the half-precision saved wavefield, as float
+static int read_half_levels(Plan &p, int shot, int first, int count, float *out)
+{
+    int rc;
+    void *tmp = nullptr;   // one haloed float level
+    if ((rc = dev_alloc(p, &tmp, (size_t)p.L.field * sizeof(float), false))) return rc;
+    const long lstride = (long)p.cfg.max_shots * p.L.field;
+    const bool dev = is_device_ptr(out);
+    for (int l = 0; l < count && !rc; ++l) {
+        const char *src = (const char *)p.saved + ((size_t)(first + l) * lstride + (size_t)shot * p.L.field) * 2;
+        float *dst = out + (long)l * p.L.ngrid;
+        rc = launch_half_to_float(p, src, (float *)tmp, p.L.field, (const float *)p.d_save_scale, shot);
+        if (!rc) rc = launch_unpack<float>(p, (const float *)tmp, p.L.field, dev ? dst : (float *)p.d_dense, 1, 0);
+        if (!rc && !dev) rc = copy_any(p, dst, p.d_dense, (size_t)p.L.ngrid * sizeof(float));
+        if (!rc && hipStreamSynchronize(p.stream) != hipSuccess) rc = fail(MIFWI_EHIP, "stream synchronisation failed");
+    }
+    dev_free(tmp);
+    return rc ? rc : finish(p);
+}
+
 template <typename T>
 static int read_wavefield(Plan &p, int which, int shot, int first, int count, void *out)
 {
@@ -1617,6 +1664,8 @@ static int read_wavefield(Plan &p, int which, int shot, int first, int count, vo
     if (which == 0) {
         if (!p.saved_valid || shot >= p.saved_shots) return fail(MIFWI_ESTATE, "no saved wavefield for this shot");
         if (p.ck_K > 0) return fail(MIFWI_ESTATE, "the forward wavefield is checkpointed, not stored level by level");
+        if (first < 0 || count < 0 || first + count > p.cfg.nt) return fail(MIFWI_EINVAL, "level range out of bounds");
+        if (p.save_f16) return read_half_levels(p, shot, first, count, (float *)out);
         base = (const T *)p.saved + (long)shot * p.L.field;
         lstride = (long)p.cfg.max_shots * p.L.field;
         nlev = p.cfg.nt;
@@ -1666,6 +1715,7 @@ static int write_wavefield(Plan &p, int shot, int first, int count, const void *
     int rc;
     if ((rc = prepare_save<T>(p))) return rc;
     if (p.ck_K > 0) return fail(MIFWI_ESTATE, "a caller-provided wavefield needs level-by-level storage, which does not fit");
+    if (p.save_f16) return fail(MIFWI_ESTATE, "a caller-provided wavefield cannot be stored with MIFWI_FLAG_SAVE_F16");
     T *base = (T *)p.saved + (long)shot * p.L.field;
     const long lstride = (long)p.cfg.max_shots * p.L.field;
     const bool dev = is_device_ptr(in);

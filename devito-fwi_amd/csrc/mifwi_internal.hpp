@@ -3,6 +3,7 @@
 #pragma once
 
 #include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
 
 #include <cstdint>
 #include <map>
@@ -125,6 +126,8 @@ struct Plan {
     // scratch [4][max_shots][field] (wA, wB, gzA, gzB)
     void *tti_par = nullptr, *tti_fwd = nullptr, *tti_adj = nullptr, *tti_tmp = nullptr;
     bool tti_fwd_valid = false, tti_adj_valid = false;
+    bool save_f16 = false;          // saved levels are half precision (MIFWI_FLAG_SAVE_F16 in effect)
+    void *d_save_scale = nullptr;   // per shot: stored half = float * scale
     void *tti_save = nullptr;   // every level of both forward fields: [field][shot][nt] (tti_forward with save)
     bool tti_save_valid = false;
     int tti_save_shots = 0;
@@ -339,6 +342,9 @@ struct Step2DArgs {
     // second, streamed copy of `out` (the saved forward level), or null
     float *copy;
     long copy_shot_stride;
+    // save_scale != nullptr: `copy` and um/uc/up are half precision, value * save_scale[shot]; their
+    // strides still count elements
+    const float *save_scale;
     // Born source term (b_un == nullptr: none): the field being advanced is the scattered one and
     // out += dt^2 * ( -dm * (b_un - 2 b_uc + b_uo) / dt^2 ) / ( m + eta dt )   (operators.py:263)
     const float *b_un, *b_uc, *b_uo, *b_dm;
@@ -381,9 +387,33 @@ struct Step3DArgs {
     // out += dt^2 * ( -dm * (b_un - 2 b_uc + b_uo) / dt^2 ) / ( m + eta dt )   (operators.py:263)
     const float *b_un, *b_uc, *b_uo, *b_dm;
     long b_shot_stride;
+    // half-precision copy of `out` (the saved forward level), or null; save_scale != nullptr also makes
+    // um/uc/up half precision; strides count elements (see Step2DArgs)
+    void *copy16;
+    long copy_shot_stride;
+    const float *save_scale;
 };
 int launch_step3d(const Plan &p, const Step3DArgs &a, hipStream_t stream);
 int launch_eta_zero(const Plan &p, unsigned char *flags);
 int step3d_blocks_per_cu(int R, bool grad);
+
+
+// ---- half-precision storage of saved levels -----------------------------------------------------
+// value -> half(value * scale), saturating at the largest finite half instead of overflowing to inf
+__device__ inline unsigned pack_half2(float a, float b)
+{
+    const float lim = 65504.0f;
+    const __half2 h = __floats2half2_rn(fminf(fmaxf(a, -lim), lim), fminf(fmaxf(b, -lim), lim));
+    return *reinterpret_cast<const unsigned *>(&h);
+}
+__device__ inline void unpack_half2(unsigned u, float &a, float &b)
+{
+    const float2 f = __half22float2(*reinterpret_cast<const __half2 *>(&u));
+    a = f.x, b = f.y;
+}
+// per-shot scale of the half-precision saved levels from the injected source terms of the whole run
+int launch_save_scale(const Plan &p, const float *winj, long per_shot, int nshots, float *scale);
+// haloed half-precision level(s) -> haloed float (divided by the shot's scale)
+int launch_half_to_float(const Plan &p, const void *src, float *dst, long n, const float *scale, int shot);
 
 }  // namespace mifwi

@@ -66,11 +66,21 @@ enum {
                                     built with fs=True (seismic/model.py:100-110,157: no absorbing
                                     layer there) and the stencil mirrors the field antisymmetrically
                                     about index 0 (seismic/acoustic/operators.py:8-35,92-94)   */
-    MIFWI_FLAG_OT4 = 32          /* 4th-order-in-time kernel: Laplacian + dt^2/12 * biharmonic(1/m)
+    MIFWI_FLAG_OT4 = 32,         /* 4th-order-in-time kernel: Laplacian + dt^2/12 * biharmonic(1/m)
                                     and the matching gradient term (seismic/acoustic/operators.py:
                                     38-56,216-219); runs on the untiled kernels; not combinable with
                                     MIFWI_FLAG_FREE_SURFACE.  The caller passes dt = 1.73 * CFL dt as
                                     the reference's solver does (wavesolver.py:41-46).             */
+    MIFWI_FLAG_SAVE_F16 = 64     /* keep the saved forward wavefield (mifwi_forward(save=1)) in IEEE
+                                    half precision, scaled per shot from the injected source terms:
+                                    half the memory (nt levels of a 592^3 grid fit one GPU) and half
+                                    the saved-level traffic of the gradient.  float32 plans on the tiled
+                                    kernels only (ignored otherwise, and when the levels do not fit
+                                    even so and checkpointing takes over).  The time stepping itself
+                                    stays float32; the gradient changes by ~5e-5 relative (rounding of
+                                    the saved levels to 11 bits).  Device-side counterpart of the
+                                    compressed wavefield serialisation of
+                                    seismic/tutorials/12_time_blocking.ipynb cells 15-37.          */
 };
 
 typedef struct mifwi_plan mifwi_plan; /* opaque */
