@@ -175,10 +175,11 @@ def _batch_entry(geometry, shots):
     # modelling always runs on the model's own time axis: the per-shot geometries the reference builds
     # (fwi.py:73-76,185-188) do not inherit geometry.resample(), which only affects the misfit sampling
     nt = _shot_geometry(geometry, 0).nt
-    from mifwi import FLAG_FREE_SURFACE
+    from mifwi import FLAG_FREE_SURFACE, FLAG_SAVE_F16
+    flags = (FLAG_FREE_SURFACE if getattr(model, 'fs', False) else 0) | (FLAG_SAVE_F16 if SAVE_HALF else 0)
     entry = engine.get_plan(model.grid.shape, model.spacing, model.grid.origin, model.space_order, nt,
                             model.critical_dt, 1, geometry.nrec, max_shots=len(shots), dtype=model.dtype,
-                            flags=FLAG_FREE_SURFACE if getattr(model, 'fs', False) else 0)
+                            flags=flags)
     vp = model.vp.data
     if np.ndim(vp) == 0:
         vp = np.full(model.grid.shape, vp, dtype=model.dtype)
@@ -203,6 +204,10 @@ def _wavelet(geometry):
 # that forms the residual on the device.  Set to False to evaluate (syn - dw) - (obs - dw) on the
 # host in float32 exactly as the reference does.
 FUSE_DIRECT_WAVE = True
+
+# Keep the saved forward wavefield in half precision on the device (half the memory; the gradient
+# changes by ~5e-5 relative on Marmousi-II).  Off by default: the default path is float32 throughout.
+SAVE_HALF = False
 
 _device_data = {}       # (plan id, ids of the shot arrays) -> (fingerprint, device tensor, arrays)
 _DEVICE_DATA_MAX = 4

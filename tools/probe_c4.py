@@ -10,6 +10,7 @@ from seismic import Model
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 so = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 nt = int(sys.argv[3]) if len(sys.argv) > 3 else 500
+flags = int(sys.argv[4]) if len(sys.argv) > 4 else 0   # e.g. 64 = half-precision saved levels
 shape = (n, n, n)
 rng = np.random.default_rng(1234)
 vp = np.empty(shape, dtype=np.float32)
@@ -24,7 +25,7 @@ src = np.array([[n * 5.0, n * 5.0, 20.0]], dtype=np.float32)
 g = np.linspace(0, (n - 1) * 10.0, 64, dtype=np.float32)
 rec = np.stack(np.meshgrid(g, g, indexing="ij"), -1).reshape(-1, 2)
 rec = np.concatenate([rec, np.full((rec.shape[0], 1), 20.0, np.float32)], 1)
-plan = mifwi.Plan(sp, model.spacing, model.grid.origin, so, nt, dt, 1, rec.shape[0], max_shots=1)
+plan = mifwi.Plan(sp, model.spacing, model.grid.origin, so, nt, dt, 1, rec.shape[0], max_shots=1, flags=flags)
 plan.set_geometry(src, rec)
 t = np.arange(nt) * dt
 r = np.pi * 0.010 * (t - 100.0)
