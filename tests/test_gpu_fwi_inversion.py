@@ -12,9 +12,8 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _example():
-    spec = importlib.util.spec_from_file_location("marmousi_fwi_example",
-                                                  os.path.join(ROOT, "examples", "marmousi_fwi.py"))
+def _example(name="marmousi_fwi"):
+    spec = importlib.util.spec_from_file_location(name + "_example", os.path.join(ROOT, "examples", name + ".py"))
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     return mod
@@ -42,6 +41,40 @@ def test_marmousi_w2_and_nlcg_run(tmp_path, capsys):
     misfit = np.loadtxt(tmp_path / "log1" / "misfit")
     assert misfit.shape == (2, 2) and misfit[1, 0] < misfit[0, 0]
     assert np.isfinite(vp).all()
+
+
+def test_marmousi2_driver_and_first_gradient(tmp_path, capsys):
+    """marmousi2_fwi.py:61-179 through the same example (--model SMARM2), with the first-gradient dump."""
+    ex = _example()
+    vp, err0, err1 = ex.main(["--model", "SMARM2", "--maxiter", "2", "--nsrc", "4", "--tn", "2000",
+                              "--check-gradient", "1", "--odir", str(tmp_path)])
+    g = np.fromfile(tmp_path / "1st_grad_0", dtype=np.float64)
+    assert g.size == 340 * 140 and np.isfinite(g).all() and np.abs(g).max() > 0
+    assert not g.reshape(340, 140)[:, :15].any()                     # bathymetry mask
+    misfit = np.loadtxt(tmp_path / "log0" / "misfit")
+    assert misfit.shape == (2, 2) and misfit[1, 0] < misfit[0, 0]
+    assert vp.shape == (340, 140) and vp.max() <= 5.0 + 1e-6
+
+
+def test_forward_modelling_driver(tmp_path, capsys):
+    """marmousi_fm.py:30-113: observed, synthetic and direct-wave gathers written as raw float32."""
+    ex = _example("marmousi_fm")
+    gathers = ex.main(["--nsrc", "3", "--tn", "1200", "--odir", str(tmp_path)])
+    nt, nrec = gathers["obs"][0].data.shape
+    assert nrec == 300
+    for name in ("obs", "syn", "direct"):
+        for i in range(3):
+            d = np.fromfile(tmp_path / "data" / (name + str(i)), dtype=np.float32).reshape(nt, nrec)
+            assert np.array_equal(d, gathers[name][i].data) and np.abs(d).max() > 0
+    assert not np.array_equal(gathers["obs"][1].data, gathers["syn"][1].data)
+
+
+def test_circle_driver(tmp_path, capsys):
+    ex = _example("circle_fwi")
+    vp, err0, err1 = ex.main(["--maxiter", "2", "--nsrc", "3", "--odir", str(tmp_path)])
+    misfit = np.loadtxt(tmp_path / "log0" / "misfit")
+    assert misfit.shape == (2, 2) and misfit[1, 0] < misfit[0, 0]
+    assert vp.shape == (201, 201) and vp.min() >= 2.5 - 1e-6 and vp.max() <= 4.0 + 1e-6
 
 
 def test_circle_workflow_with_resampled_traces(tmp_path, capsys):
