@@ -163,3 +163,52 @@ def test_fwi_obj_single_matches_batched():
         g_s += g_
     assert abs(f_b - f_s) <= 1e-5 * abs(f_s)
     assert rel_l2(g_b, g_s.ravel()) < 1e-5
+
+
+@pytest.mark.parametrize("with_direct", [False, True])
+def test_wasserstein_device_route_matches_host_route(with_direct):
+    """fwi_obj_multi with the trace-wise W2 misfit: evaluating the misfit for all shots on the device
+    (qWasserstein.batch_device) gives the objective, gradient and adjoint sources of the shot-by-shot host
+    loop (reference fwi.py:131-205 with misfit/misfit.py:49-104).  The host loop works in the data's
+    float32 (cumulative sums over the trace included), the device form in float64, so they differ by the
+    float32 rounding of the host route: tolerances 1e-3 (objective), 1e-2 (gradient, adjoint sources);
+    against the host loop fed float64 copies of the same gathers the device form agrees to 1e-9 / 1e-5."""
+    import fwi
+    from fwi import fm_multi, fwi_obj_multi
+    from misfit import qWasserstein
+    from seismic import Model, AcquisitionGeometry
+    c = _marmousi_like()
+    obs = fm_multi(c["g1"], save=False)
+    direct = None
+    if with_direct:
+        cm = Model(vp=np.ones(c["true_vp"].shape) * 1.5, origin=(0, 0), spacing=c["spacing"],
+                   shape=c["true_vp"].shape, space_order=c["so"], nbl=c["nbl"], fs=False, dt=c["dt"])
+        direct = fm_multi(AcquisitionGeometry(cm, c["rec"], c["src"], 0., 900., f0=0.007, src_type='Ricker'))
+    w2 = qWasserstein(gamma=1.01, method='1d')
+    out = {}
+    try:
+        for flag in (True, False):
+            fwi.DEVICE_MISFIT = flag
+            f, g, res = fwi_obj_multi(c["g0"], obs, w2, direct, c["mask"], True, True)
+            out[flag] = (f, g, [np.asarray(r) for r in res])
+            f2, _, _ = fwi_obj_multi(c["g0"], obs, w2, direct, c["mask"], True, False)
+            assert abs(f2 - f) <= 1e-9 * abs(f)
+    finally:
+        fwi.DEVICE_MISFIT = True
+    assert out[True][0] > 0 and abs(out[True][0] - out[False][0]) <= 1e-3 * out[False][0]
+    print("W2 device vs host route: objective %.2e gradient %.2e" % (
+        abs(out[True][0] - out[False][0]) / out[False][0], rel_l2(out[True][1], out[False][1])))
+    assert rel_l2(out[True][1], out[False][1]) <= 1e-2
+    for a, b in zip(out[True][2], out[False][2]):
+        assert a.shape == b.shape and rel_l2(a, b) <= 1e-2
+    # the same gathers through the host loop in float64
+    syn = fm_multi(c["g0"], save=False)
+    total = 0.0
+    for i in range(len(syn)):
+        s_, o_ = syn[i].data.astype(np.float64), obs[i].data.astype(np.float64)
+        if direct is not None:
+            s_, o_ = s_ - direct[i].data.astype(np.float32), o_ - direct[i].data.astype(np.float32)
+        f_, r_ = w2(s_, o_)
+        total += f_
+        assert rel_l2(out[True][2][i], r_) <= 1e-5
+    assert abs(out[True][0] - total) <= 1e-7 * total

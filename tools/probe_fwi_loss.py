@@ -6,7 +6,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "devito-fwi_amd")]
 from seismic import Model, AcquisitionGeometry
 from fwi import fm_multi, fwi_loss
-from misfit import least_square
+from misfit import least_square, qWasserstein
 
 so = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 nshots = 8
@@ -36,3 +36,14 @@ for dw, label in ((None, "no direct wave"), (direct, "with direct wave")):
         t = time.perf_counter(); f2, _, _ = fwi_loss(m0, g0, obs, least_square, dw, mask, True, calc_grad=False); tf.append(time.perf_counter() - t)
     print("%-18s fwi_loss grad %.1f ms, forward-only %.1f ms (fm_multi first call %.0f ms)  fval %.6e |g| %.4e" %
           (label, min(ts) * 1e3, min(tf) * 1e3, t_obs * 1e3, f, np.linalg.norm(g)), flush=True)
+
+w2 = qWasserstein(gamma=1.01, method='1d')
+fwi_loss(m0, g0, obs, w2, None, mask, True)
+ts = []
+for _ in range(2):
+    t = time.perf_counter(); f, g, r = fwi_loss(m0, g0, obs, w2, None, mask, True); ts.append(time.perf_counter() - t)
+t = time.perf_counter()
+for k in range(nshots):
+    w2(np.asarray(r[k]), obs[k].data)
+tm = time.perf_counter() - t
+print("trace-wise W2 misfit: fwi_loss grad %.1f ms, of which the misfit calls themselves ~%.1f ms   fval %.6e" % (min(ts) * 1e3, tm * 1e3, f))
