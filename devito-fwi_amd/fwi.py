@@ -12,9 +12,9 @@ illumination and objective); for the least-squares misfit the residual never lea
 from copy import deepcopy
 
 import numpy as np
-from scipy import interpolate
 
 from seismic import Receiver, AcquisitionGeometry, Function
+from seismic.source import spline_resample
 from seismic.acoustic import AcousticWaveSolver
 from misfit import least_square
 
@@ -70,11 +70,7 @@ def resample(x, t, t0, order=3):
     dt0 = t0[1] - t0[0]
     if np.isclose(dt, dt0):
         return x
-    new_x = np.zeros((t.size, x.shape[1]), dtype=np.float32)
-    for i in range(x.shape[1]):
-        tck = interpolate.splrep(t0, x[:, i], k=order)
-        new_x[:, i] = interpolate.splev(t, tck)
-    return new_x
+    return spline_resample(x, t0, t, order).astype(np.float32)
 
 
 _MUTE_CACHE = {}
@@ -220,6 +216,7 @@ _DEVICE_DATA_MAX = 4
 def clear_caches():
     """Forget the device-resident copies of observed data."""
     _device_data.clear()
+    _resampled_data.clear()
 
 
 def _resident_batch(plan, objs, shots, dtype):
@@ -373,6 +370,25 @@ def fm_multi(geometry, save=False):
     return shots
 
 
+_resampled_data = {}     # (id of the data array, dt) -> (fingerprint, resampled object, array)
+
+
+def _resampled(obj, dt):
+    """obj.resample(dt), remembered for as long as the same data array is passed with unchanged content
+    (observed and direct-wave gathers are resampled identically at every objective evaluation)."""
+    arr = obj.data
+    key = (id(arr), float(dt))
+    finger = float(np.asarray(arr).reshape(-1)[::251].sum(dtype=np.float64))
+    hit = _resampled_data.get(key)
+    if hit is not None and hit[0] == finger:
+        return hit[1]
+    out = obj.resample(dt)
+    while len(_resampled_data) >= 256:
+        _resampled_data.pop(next(iter(_resampled_data)))
+    _resampled_data[key] = (finger, out, arr)
+    return out
+
+
 def fwi_obj_single(geometry, obs, misfit_func, direct_wave=None, resample_dt=None, calc_grad=False):
     """Objective, muted gradient, residual and muted illumination of one shot
     (reference fwi.py:131-173)."""
@@ -382,10 +398,10 @@ def fwi_obj_single(geometry, obs, misfit_func, direct_wave=None, resample_dt=Non
     if resample_dt is None:
         resample_dt = geometry.dt
     else:
-        obs = deepcopy(obs).resample(resample_dt)
+        obs = _resampled(obs, resample_dt)
         pred = pred.resample(resample_dt)
         if direct_wave is not None:
-            dw = deepcopy(direct_wave).resample(resample_dt)
+            dw = _resampled(direct_wave, resample_dt)
     syn_data = pred.data
     obs_data = obs.data
     pred_times = pred.time_values
@@ -404,11 +420,14 @@ def fwi_obj_single(geometry, obs, misfit_func, direct_wave=None, resample_dt=Non
     illum, crop_grad = None, None
     if calc_grad:
         grad = Function(name="grad", grid=geometry.model.grid)
-        solver.gradient(rec=residual, u=wfd, vp=geometry.model.vp, grad=grad)
+        # sum over time of u^2 (fwi.py:171 of the reference reduces the saved wavefield on the host):
+        # accumulated by the gradient kernel while the wavefield is still on the device
+        illum_f = Function(name="illum", grid=geometry.model.grid)
+        solver.gradient(rec=residual, u=wfd, vp=geometry.model.vp, grad=grad, illum=illum_f)
         crop = geometry.model.physical_slices
         crop_grad = np.array(grad.data[:])[crop]
         crop_grad = fix_source_illumination(geometry, crop_grad)
-        illum = (wfd.data * wfd.data).sum(axis=0)[crop]
+        illum = np.array(illum_f.data[:])[crop]
         illum = fix_source_illumination(geometry, illum)
     return fval, crop_grad, residual.data, illum
 

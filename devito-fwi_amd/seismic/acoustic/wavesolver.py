@@ -126,9 +126,10 @@ class AcousticWaveSolver(object):
             v.data[...] = entry.plan.read_wavefield(2, shot=0)
         return srca, out_v, PerformanceSummary(entry.plan.stats())
 
-    def jacobian_adjoint(self, rec, u, v=None, grad=None, vp=None, checkpointing=False, **kwargs):
+    def jacobian_adjoint(self, rec, u, v=None, grad=None, vp=None, checkpointing=False, illum=None, **kwargs):
         """Adjoint Jacobian (FWI gradient); accumulates into `grad` and returns (grad, summary)
-        (wavesolver.py:153-205)."""
+        (wavesolver.py:153-205).  Extension: a Function passed as `illum` also receives (is incremented
+        by) the sum over time of u^2, which the gradient kernel forms from the saved wavefield anyway."""
         if checkpointing:
             raise NotImplementedError("pyrevolve checkpointing is not available; the saved wavefield stays on the GPU")
         dt = kwargs.pop('dt', self.dt)
@@ -142,8 +143,10 @@ class AcousticWaveSolver(object):
             entry.claim(0)
             entry.plan.write_wavefield(ud, shot=0)
         entry.claim(2)
-        entry.plan.gradient(rec.data[None], nshots=1, grad=grad.data.reshape((1,) + grad.data.shape),
-                            accumulate=True)
+        out = entry.plan.gradient(rec.data[None], nshots=1, grad=grad.data.reshape((1,) + grad.data.shape),
+                                  accumulate=True, want_illum=illum is not None)
+        if illum is not None:
+            illum.data[...] += out[1][0]
         if v is not None:
             v.data[...] = entry.plan.read_wavefield(2, shot=0)
         return grad, PerformanceSummary(entry.plan.stats())

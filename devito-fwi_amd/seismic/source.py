@@ -119,16 +119,38 @@ class PointSource(object):
             new_range = TimeAxis(start=start, stop=stop, step=dt)
         if np.isclose(dt, dt0):
             return self
-        traces = np.zeros((new_range.num, self.npoint))
-        for i in range(self.npoint):
-            tck = interpolate.splrep(self._time_range.time_values, self.data[:, i], k=order)
-            traces[:, i] = interpolate.splev(new_range.time_values, tck)
+        traces = spline_resample(self.data, self._time_range.time_values, new_range.time_values, order)
         return PointSource(name=self.name, grid=self.grid, data=traces, time_range=new_range,
                            coordinates=self.coordinates.data)
 
 
 Receiver = PointSource
 Shot = PointSource
+
+
+_SPLINE_OPS = {}
+_SPLINE_OPS_MAX = 8
+
+
+def spline_resample(x, t0, t, order=3):
+    """Interpolating spline of degree `order` through the columns of x(t0), evaluated at t: what
+    `splev(t, splrep(t0, x[:, i], k=order))` gives for every column i (source.py:160-166 of the reference),
+    to ~1e-15.  Interpolation is linear in the data, so the map t0 -> t is formed once per pair of time axes
+    as a sparse matrix (a sample's influence decays by 0.27 per knot for cubics; entries below 1e-17 of the
+    largest are dropped) and every later call is one sparse product instead of a spline fit per trace."""
+    from scipy import sparse
+    t0 = np.ascontiguousarray(t0, dtype=np.float64)
+    t = np.ascontiguousarray(t, dtype=np.float64)
+    key = (t0.size, t.size, int(order), t0.tobytes()[:64], t0[-1], t.tobytes()[:64], t[-1])
+    op = _SPLINE_OPS.get(key)
+    if op is None:
+        dense = interpolate.make_interp_spline(t0, np.eye(t0.size), k=order, axis=0)(t)
+        dense[np.abs(dense) < 1e-17 * np.abs(dense).max()] = 0.0
+        op = sparse.csr_matrix(dense)
+        while len(_SPLINE_OPS) >= _SPLINE_OPS_MAX:
+            _SPLINE_OPS.pop(next(iter(_SPLINE_OPS)))
+        _SPLINE_OPS[key] = op
+    return op @ np.asarray(x, dtype=np.float64)
 
 
 class WaveletSource(PointSource):

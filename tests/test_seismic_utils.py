@@ -199,3 +199,29 @@ def test_qwasserstein_batched_form_matches_trace_loop(trans):
         loss, grad = w2(f[k], g[k])
         assert abs(float(loss_b[k]) - loss) <= 1e-9 * max(1e-3, abs(loss))
         assert np.linalg.norm(grad_b[k].numpy() - grad) <= 1e-6 * np.linalg.norm(grad)
+
+
+@pytest.mark.parametrize("order", [1, 3, 5])
+def test_spline_resample_equals_per_trace_fit(order):
+    """seismic.source.spline_resample (one cached sparse operator per pair of time axes) against the
+    per-trace splrep/splev of the reference (source.py:160-166, fwi.py:47-57): 1e-12 relative."""
+    from scipy import interpolate
+    from seismic.source import spline_resample
+    rng = np.random.default_rng(6)
+    t0 = np.arange(700) * 0.6897
+    t = np.arange(0, 482) * 1.0
+    x = np.cumsum(rng.standard_normal((700, 9)), axis=0).astype(np.float32)
+    ref = np.stack([interpolate.splev(t, interpolate.splrep(t0, x[:, i], k=order)) for i in range(9)], axis=1)
+    for _ in range(2):                                      # second call takes the cached operator
+        out = spline_resample(x, t0, t, order)
+        assert out.shape == ref.shape and np.abs(out - ref).max() <= 1e-12 * np.abs(ref).max()
+    # and through the Receiver object
+    from seismic import Receiver, TimeAxis, demo_model
+    model = demo_model('constant-isotropic', shape=(21, 21), spacing=(10., 10.), nbl=2)
+    rec = Receiver(name='r', grid=model.grid, time_range=TimeAxis(start=0., step=0.6897, num=700),
+                   coordinates=np.zeros((9, 2)))
+    rec.data[:] = x
+    rs = rec.resample(dt=1.0)
+    tt = rs.time_values
+    ref2 = np.stack([interpolate.splev(tt, interpolate.splrep(t0, x[:, i], k=3)) for i in range(9)], axis=1)
+    assert np.abs(rs.data - ref2).max() <= 1e-5 * np.abs(ref2).max()
