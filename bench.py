@@ -131,6 +131,84 @@ def roofline_3d(mifwi, device, space_order=16, n=512, nbl=40, nt=14):
                         % (n, nbl, sp[0], space_order)}
 
 
+def tti_leg(mifwi, device, true_model, src, rec, space_order=8, nshots=2):
+    """2-D TTI on the Marmousi-II grid at space order 8, two shots (the per-GPU share of 16 shots on 8 GPUs):
+    forward with both fields saved + gradient (Jacobian adjoint), full nt.  The reference ships no anisotropy
+    rasters for Marmousi-II, so epsilon, delta and theta follow its `layers-tti` recipe applied to vp."""
+    from seismic import Model, AcquisitionGeometry
+    vp = np.asarray(true_model.vp.data[true_model.nbl:-true_model.nbl, true_model.nbl:-true_model.nbl], np.float32)
+    scale = float(vp.max() - 1.5)
+    model = Model(origin=(0, 0), spacing=true_model.spacing, shape=vp.shape, space_order=space_order, vp=vp,
+                  nbl=true_model.nbl, bcs="damp", epsilon=0.3 * (vp - 1.5) / scale, delta=0.2 * (vp - 1.5) / scale,
+                  theta=0.5 * (vp - 1.5) / scale)
+    dt = float(model.critical_dt)
+    geom = AcquisitionGeometry(model, rec, src[0], 0., 4500., f0=0.007, src_type='Ricker')
+    nt = geom.nt
+    wavelet = np.ascontiguousarray(geom.src.data)
+    plan = mifwi.Plan(model.grid.shape, model.spacing, model.grid.origin, space_order, nt, dt, 1, rec.shape[0],
+                      max_shots=nshots, device=device)
+    plan.set_model(model.vp.data, model.damp.data)
+    plan.tti_set_model(model.epsilon.data, model.delta.data, model.theta.data)
+    plan.set_geometry(np.asarray(src[:nshots], np.float32).reshape(nshots, 1, 2), rec)
+    ngrid = float(np.prod(model.grid.shape))
+    best = None
+    for _ in range(3):
+        t0 = time.perf_counter()
+        d = plan.tti_forward(wavelet, save=True)
+        fwd = plan.stats()["fwd_ms"]
+        plan.tti_gradient(d)
+        bwd = plan.stats()["bwd_ms"]
+        wall = (time.perf_counter() - t0) * 1e3
+        if best is None or wall < best[0]:
+            best = (wall, fwd, bwd)
+    plan.close()
+    pts = 2.0 * (nt - 2) * ngrid * nshots
+    return {"workload": "2-D TTI ('centered' kernel) on the Marmousi-II grid %s, space_order=%d, dt=%.3f ms, nt=%d, "
+                        "%d shots: forward with both fields saved + Jacobian-adjoint gradient" %
+                        (list(model.grid.shape), space_order, dt, nt, nshots),
+            "gpoints_per_s": pts / (best[0] * 1e-3) / 1e9, "wall_ms": best[0], "forward_loop_ms": best[1],
+            "gradient_loop_ms": best[2], "forward_us_per_step": best[1] / (nt - 2) * 1e3,
+            "gradient_us_per_step": best[2] / (nt - 2) * 1e3,
+            "algorithmic_bytes_per_point": {"forward": 64, "gradient": 80}}
+
+
+def c4_leg(mifwi, device, space_order=8, n=512, nbl=40, nt=500):
+    """Synthetic 3-D 512^3 (+ sponge = 592^3), space order 8, one shot, nt = 500: forward + L2 gradient through
+    the C ABI.  500 float32 levels (415 GB) do not fit one GPU, so the default path checkpoints and recomputes."""
+    from seismic import Model
+    shape = (n, n, n)
+    vp = np.empty(shape, dtype=np.float32)
+    vp[:] = np.linspace(1.5, 4.5, n, dtype=np.float32)[None, None, :]
+    kw = dict(origin=(0., 0., 0.), spacing=(10., 10., 10.), shape=shape, space_order=space_order, nbl=nbl, bcs="damp")
+    model, model0 = Model(vp=vp, **kw), Model(vp=np.full(shape, 3.0, dtype=np.float32), **kw)
+    dt = float(model.critical_dt)
+    sp = model.grid.shape
+    src = np.array([[n * 5.0, n * 5.0, 20.0]], dtype=np.float32)
+    g = np.linspace(0, (n - 1) * 10.0, 64, dtype=np.float32)
+    rec = np.stack(np.meshgrid(g, g, indexing="ij"), -1).reshape(-1, 2)
+    rec = np.concatenate([rec, np.full((rec.shape[0], 1), 20.0, np.float32)], 1)
+    plan = mifwi.Plan(sp, model.spacing, model.grid.origin, space_order, nt, dt, 1, rec.shape[0], max_shots=1,
+                      device=device)
+    plan.set_geometry(src, rec)
+    t = np.arange(nt) * dt
+    r = np.pi * 0.010 * (t - 100.0)
+    wav = ((1 - 2 * r ** 2) * np.exp(-r ** 2)).astype(np.float32).reshape(nt, 1)
+    plan.set_model(model.vp.data, model.damp.data)
+    obs = plan.forward(wav)
+    plan.set_model(model0.vp.data, model0.damp.data)
+    t0 = time.perf_counter()
+    out = plan.l2_misfit_gradient(wav, obs, want_illum=False)
+    wall = time.perf_counter() - t0
+    st = plan.stats()
+    plan.close()
+    pts = 2.0 * (nt - 2) * float(np.prod(sp))
+    return {"workload": "synthetic 3-D %d^3 (+nbl %d = %d^3), space_order=%d, nt=%d, 1 shot: forward + L2 gradient, "
+                        "two-level checkpointing (the saved wavefield would be 415 GB)" % (n, nbl, sp[0], space_order, nt),
+            "gpoints_per_s": pts / wall / 1e9, "wall_ms": wall * 1e3, "forward_loop_ms": st["fwd_ms"],
+            "gradient_loop_ms_incl_recomputation": st["bwd_ms"], "device_bytes": st["device_bytes"],
+            "objective": float(out["fval"][0])}
+
+
 def fwi_iteration(true_model, init_model, src_all, rec, k=3, reps=3):
     """Wall time of one FWI iteration through the drop-in Python API (fwi.fwi_loss): one
     objective+gradient evaluation followed by k forward-only line-search evaluations, all shots of
@@ -167,7 +245,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--space-order", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-3d", action="store_true", help="skip the 3-D stencil roofline measurement")
+    ap.add_argument("--no-3d", action="store_true", help="skip the 3-D measurements (stencil roofline, 512^3 gradient)")
+    ap.add_argument("--no-tti", action="store_true", help="skip the 2-D TTI measurement")
     ap.add_argument("--flags", type=int, default=0, help="MIFWI_FLAG_* bits for the plan (debugging)")
     args = ap.parse_args()
 
@@ -327,6 +406,9 @@ def main():
     if rank == 0 and world == 1 and not args.no_3d:
         # the north-star stencil: 16th-order 3-D forward step against the HBM roofline
         out["roofline_3d"] = roofline_3d(mifwi, local_rank, space_order=16)
+        out["config_3d_512"] = c4_leg(mifwi, local_rank)
+    if rank == 0 and world == 1 and not args.no_tti:
+        out["config_tti_2d"] = tti_leg(mifwi, local_rank, true_model, src_all, rec)
     if rank == 0:
         print(json.dumps(out))
     if use_dist:
