@@ -353,6 +353,8 @@ static int launch_r(const Plan &p, const Step2DArgs &a, int nblocks, hipStream_t
     if (p.tile_tz == 64) return launch_rt<R, 16, 64>(p, a, nblocks, stream);
     if (p.tile_tx == 48) return launch_rt<R, 48, 32>(p, a, nblocks, stream);
     if (p.tile_tx == 24) return launch_rt<R, 24, 32>(p, a, nblocks, stream);
+    if (p.tile_tx == 16) return launch_rt<R, 16, 32>(p, a, nblocks, stream);
+    if (p.tile_tx == 8) return launch_rt<R, 8, 32>(p, a, nblocks, stream);
     return launch_rt<R, 32, 32>(p, a, nblocks, stream);
 }
 

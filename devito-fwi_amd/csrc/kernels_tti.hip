@@ -417,6 +417,8 @@ static int launch_tti2d_r(const Plan &p, const Tti2DArgs &a, int fwd)
         return MIFWI_EINVAL;
     }
     if (p.tile_tz == 64) launch_tti2d_rt<R, 16, 64>(p, a, fwd, nblocks);
+    else if (p.tile_tx == 16) launch_tti2d_rt<R, 16, 32>(p, a, fwd, nblocks);
+    else if (p.tile_tx == 8) launch_tti2d_rt<R, 8, 32>(p, a, fwd, nblocks);
     else launch_tti2d_rt<R, 32, 32>(p, a, fwd, nblocks);
     MIFWI_HIP(hipGetLastError());
     return MIFWI_OK;
@@ -424,7 +426,8 @@ static int launch_tti2d_r(const Plan &p, const Tti2DArgs &a, int fwd)
 
 bool tti2d_available(const Plan &p)
 {
-    return p.kind == 1 && ((p.tile_tx == 32 && p.tile_tz == 32) || (p.tile_tx == 16 && p.tile_tz == 64));
+    return p.kind == 1 && ((p.tile_tx == 32 && p.tile_tz == 32) || (p.tile_tx == 16 && p.tile_tz == 64) ||
+                           ((p.tile_tx == 16 || p.tile_tx == 8) && p.tile_tz == 32));
 }
 
 static int launch_tti2d(const Plan &p, const StepConsts<float> &k, const TtiParams<float> &q, int fwd,

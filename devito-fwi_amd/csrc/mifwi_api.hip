@@ -550,6 +550,9 @@ static int set_geometry(Plan &p, int nshots, const void *src_coords, const void 
     if (!rc_.empty()) MIFWI_HIP(hipMemcpy(rc_.data(), rec_coords, rc_.size() * sizeof(T), hipMemcpyDefault));
     int rc;
     clear_graphs(p);  // captured loops hold pointers into the geometry tables
+    p.geo_src.assign((const unsigned char *)sc.data(), (const unsigned char *)(sc.data() + sc.size()));
+    p.geo_rec.assign((const unsigned char *)rc_.data(), (const unsigned char *)(rc_.data() + rc_.size()));
+    p.geo_rec_per_shot = rec_per_shot;
     if ((rc = build_sparse<T>(p, p.src, sc.data(), p.cfg.nsrc, nshots, 1))) return rc;
     if ((rc = build_sparse<T>(p, p.rec, rc_.data(), p.cfg.nrec, rec_per_shot ? nshots : 1, rec_per_shot ? 1 : 0)))
         return rc;
@@ -1337,6 +1340,25 @@ static int tti_set_model(Plan &p, const void *eps, const void *delta, const void
         return fail(MIFWI_EINVAL, "TTI is not available with a free surface or the OT4 kernel");
     if (!eps || !delta || !theta) return fail(MIFWI_EINVAL, "epsilon, delta and theta are required");
     int rc;
+    if (p.kind == 1 && !p.tti_par && !getenv("MIFWI_2D_TX")) {
+        // The TTI kernel holds two fields and four product arrays of a tile in LDS, so it runs best on small
+        // tiles: 8 x 32 was the fastest shape at space orders up to 8 for every batch size, and at higher
+        // orders whenever the batch leaves the GPU under-filled (measured on MI355X, Marmousi-II grid: 2 shots
+        // at order 8 10.1 -> 6.4 us per step, at order 16 12.8 -> 8.8; 8 shots at order 16 17.0 -> 18.6, hence
+        // the condition).  The acoustic kernels of the same plan lose <= 3 % on that shape.
+        const int t32 = ((p.L.n[1] + 31) / 32) * ((p.L.n[2] + 31) / 32);
+        if ((p.L.R <= 4 || (long)p.cfg.max_shots * t32 <= 2L * p.ncu) && !(p.tile_tx == 8 && p.tile_tz == 32)) {
+            clear_graphs(p);
+            p.tile_tx = 8, p.tile_tz = 32;
+            p.ntx = (p.L.n[1] + 7) / 8, p.ntz = (p.L.n[2] + 31) / 32;
+            if (p.have_geometry) {   // the sparse tables are per tile: rebuild them from the kept coordinates
+                if ((rc = build_sparse<T>(p, p.src, (const T *)p.geo_src.data(), p.cfg.nsrc, p.geom_shots, 1))) return rc;
+                if ((rc = build_sparse<T>(p, p.rec, (const T *)p.geo_rec.data(), p.cfg.nrec,
+                                          p.geo_rec_per_shot ? p.geom_shots : 1, p.geo_rec_per_shot ? 1 : 0)))
+                    return rc;
+            }
+        }
+    }
     const size_t fb = (size_t)p.L.field * sizeof(T), S = (size_t)p.cfg.max_shots;
     if (!p.tti_par) {
         if ((rc = dev_alloc(p, &p.tti_par, 6 * fb, true))) return rc;

@@ -126,6 +126,10 @@ struct Plan {
     // scratch [4][max_shots][field] (wA, wB, gzA, gzB)
     void *tti_par = nullptr, *tti_fwd = nullptr, *tti_adj = nullptr, *tti_tmp = nullptr;
     bool tti_fwd_valid = false, tti_adj_valid = false;
+    // host copies of the coordinates last given to mifwi_set_geometry (the sparse tables depend on the tile
+    // shape, which the first mifwi_tti_set_model may change)
+    std::vector<unsigned char> geo_src, geo_rec;
+    int geo_rec_per_shot = 0;
     bool save_f16 = false;          // saved levels are half precision (MIFWI_FLAG_SAVE_F16 in effect)
     void *d_save_scale = nullptr;   // per shot: stored half = float * scale
     void *tti_save = nullptr;   // every level of both forward fields: [field][shot][nt] (tti_forward with save)
