@@ -14,11 +14,11 @@ class qWasserstein(object):
 
     method='1d' compares trace by trace (each column of an (nt, ntr) gather) through the
     closed-form 1-D optimal map; the signals are first made positive by `trans_type`
-    ('linear' shifts by gamma * |min|, 'square', 'exp', 'softplus'). method='2d' needs the
-    back-and-forth optimal-transport solver the reference takes from an external module
-    (misfit/bfm.py:1) and is not provided: such an object can be built but raises when called.
+    ('linear' shifts by gamma * |min|, 'square', 'exp', 'softplus'). method='2d' treats the whole gather
+    as one density on the unit square and solves the transport problem with the back-and-forth method
+    (misfit/bfm.py here; misfit/misfit.py:71-81 and misfit/bfm.py of the reference).
 
-    No output of the reference exists for this misfit in its repository, so the numbers are
+    No output of the reference exists for these misfits in its repository, so the numbers are
     checked against finite differences and closed forms only (parity unpinned).
     """
 
@@ -27,6 +27,8 @@ class qWasserstein(object):
         self.gamma = gamma
         self.method = method
         self.trans_type = trans_type
+        self.num_steps, self.step_scale = num_steps, step_scale
+        self.bfm = None            # built on first use: its helper library is only needed for method='2d'
 
     def _transform(self, f, g):
         """Positive densities mu(f), nu(g) and d mu / d f (misfit/misfit.py:21-47)."""
@@ -109,13 +111,18 @@ class qWasserstein(object):
         return loss.reshape(ns, ntr).sum(dim=1), grad.to(f.dtype).contiguous()
 
     def __call__(self, f, g):
-        if self.method == '2d':
-            # constructing the object must work (the reference's drivers build both variants up front,
-            # marmousi_fwi.py:130-132); only its use is unavailable
-            raise NotImplementedError("the 2-D (back-and-forth) Wasserstein misfit is not provided; "
-                                      "use method='1d' or least_square")
         shape = f.shape
+        if self.method == '2d' and (f.ndim == 1 or shape[1] <= 1):
+            raise ValueError("Can not use 2d method for 1D input.")
         mu, nu, d = self._transform(f, g)
+        if self.method == '2d':
+            # misfit/misfit.py:71-81: the solver normalises both densities itself; its derivative is divided
+            # by the mean of mu once more, as the reference does
+            if self.bfm is None:
+                from .bfm import bfm
+                self.bfm = bfm(num_steps=self.num_steps, step_scale=self.step_scale)
+            loss, grad = self.bfm.gradient(mu, nu)
+            return loss, grad / (mu.sum() / mu.size) * d
         if f.ndim == 1 or shape[1] <= 1:
             loss, grad = self._trace(np.squeeze(mu), np.squeeze(nu))
             return loss, grad.reshape(shape) * d

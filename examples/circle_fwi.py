@@ -20,7 +20,8 @@ from optimize import LBFGS                               # noqa: E402
 from minimize import minimize                            # noqa: E402
 
 parser = argparse.ArgumentParser(description='Full waveform inversion of a circular anomaly')
-parser.add_argument('--misfit', type=int, default=0, choices=[0, 1], help='0=least squares, 1=trace-wise W2')
+parser.add_argument('--misfit', type=int, default=0, choices=[0, 1, 2],
+                    help='0=least squares, 1=trace-wise W2, 2=2-D W2 of the whole gather (back-and-forth method)')
 parser.add_argument('--precond', type=int, default=1)
 parser.add_argument('--odir', type=str, default='./result/circle')
 parser.add_argument('--bathy', type=int, default=1)
@@ -56,7 +57,8 @@ def main(argv=None):
     geometry1.resample(resample_dt)
     geometry0.resample(resample_dt)
     obs = fm_multi(geometry1, save=False)
-    misfit_func = least_square if args.misfit == 0 else qWasserstein(gamma=1.01, method='1d')
+    misfit_func = (least_square, qWasserstein(gamma=1.01, method='1d'),
+                   qWasserstein(gamma=1.01, method='2d', num_steps=10, step_scale=1.))[args.misfit]
     if args.check_gradient:
         f, g, _ = fwi_obj_multi(geometry0, obs, misfit_func, None, mask, args.precond, True)
         g.tofile(os.path.join(args.odir, 'circle_1st_grad_' + str(args.misfit)))

@@ -25,7 +25,8 @@ parser = argparse.ArgumentParser(description='Full waveform inversion')
 parser.add_argument('--model', default='SMARMN', choices=sorted(common.CONFIGS))
 parser.add_argument('--data', default=None, help='directory holding vp.true and vp.smooth_20 (default: the fixtures)')
 parser.add_argument('--check-gradient', type=int, default=0, help='1: also write the first gradient to odir')
-parser.add_argument('--misfit', type=int, default=0, choices=[0, 1], help='0=least squares, 1=trace-wise W2')
+parser.add_argument('--misfit', type=int, default=0, choices=[0, 1, 2],
+                    help='0=least squares, 1=trace-wise W2, 2=2-D W2 of the whole gather (back-and-forth method)')
 parser.add_argument('--method', default='LBFGS', choices=['LBFGS', 'NLCG', 'SteepestDescent'])
 parser.add_argument('--precond', type=int, default=1)
 parser.add_argument('--odir', type=str, default=None, help='default ./result/<model>')
@@ -61,7 +62,8 @@ def main(argv=None):
 
     obs = fm_multi(geometry1, save=False)
     direct_wave = fm_multi(geometry2, save=False)
-    misfit_func = least_square if args.misfit == 0 else qWasserstein(gamma=1.01, method='1d')
+    misfit_func = (least_square, qWasserstein(gamma=1.01, method='1d'),
+                   qWasserstein(gamma=1.01, method='2d', num_steps=10, step_scale=1.))[args.misfit]
 
     if args.check_gradient:
         f, g, _ = fwi_obj_multi(geometry0, obs, misfit_func, direct_wave, bathy_mask, args.precond, True)

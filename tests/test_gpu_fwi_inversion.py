@@ -43,6 +43,17 @@ def test_marmousi_w2_and_nlcg_run(tmp_path, capsys):
     assert np.isfinite(vp).all()
 
 
+def test_marmousi_2d_wasserstein_runs(tmp_path, capsys):
+    """--misfit 2 of the reference's drivers (marmousi_fwi.py:130-140): the whole gather as one density,
+    back-and-forth optimal transport for the adjoint source."""
+    ex = _example()
+    vp, err0, err1 = ex.main(["--maxiter", "2", "--nsrc", "3", "--tn", "1500", "--misfit", "2",
+                              "--odir", str(tmp_path)])
+    misfit = np.loadtxt(tmp_path / "log2" / "misfit")
+    assert misfit.shape == (2, 2) and misfit[1, 0] < misfit[0, 0]
+    assert np.isfinite(vp).all()
+
+
 def test_marmousi2_driver_and_first_gradient(tmp_path, capsys):
     """marmousi2_fwi.py:61-179 through the same example (--model SMARM2), with the first-gradient dump."""
     ex = _example()

@@ -153,8 +153,8 @@ def test_qwasserstein_1d_closed_forms():
     corr = np.corrcoef(fd, adj2[idx, 0])[0, 1]
     assert corr > 0.9
     w2d = qWasserstein(gamma=1.01, method='2d', num_steps=15, step_scale=1.)     # as the drivers build it
-    with pytest.raises(NotImplementedError):
-        w2d(f, g)
+    loss2d, adj2d = w2d(f, g)                                                     # details: tests/test_w2_2d.py
+    assert loss2d > 0 and adj2d.shape == f.shape and np.isfinite(adj2d).all()
     assert Misfit(least_square)(np.ones(3), np.zeros(3))[0] == pytest.approx(1.5)
 
 
