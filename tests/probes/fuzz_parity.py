@@ -2,7 +2,7 @@
 counts, receiver layouts, free surface, half-precision saving, TTI).  Prints the worst relative errors."""
 import os, sys
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "devito-fwi_amd"), os.path.join(ROOT, "tests")]
 import mifwi
 from helpers import Case, rel_l2, smooth_random_vp

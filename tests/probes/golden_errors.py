@@ -1,7 +1,7 @@
 """Print the GPU-vs-golden relative errors for every golden case (tolerance calibration)."""
 import os, sys
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "devito-fwi_amd"), os.path.join(ROOT, "tests")]
 import mifwi
 from golden_cases import CASES, load

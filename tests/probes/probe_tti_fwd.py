@@ -1,7 +1,7 @@
 """GPU probe: tiled TTI forward step time only (2-D, 8 shots), for kernel experiments."""
 import os, sys
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "devito-fwi_amd"), os.path.join(ROOT, "tests")]
 import mifwi
 from helpers import smooth_random_vp

@@ -2,7 +2,7 @@
 OT4, TTI) on a Marmousi-II-sized 2-D grid (8 shots) and a 256^3 + sponge 3-D grid (1 shot)."""
 import os, sys
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "devito-fwi_amd"), os.path.join(ROOT, "tests")]
 import mifwi
 from helpers import smooth_random_vp
