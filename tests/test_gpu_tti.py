@@ -147,6 +147,26 @@ def test_tti_requires_model_and_order(mifwi):
     plan.set_geometry(np.array([[[100., 100.]]], np.float32), np.array([[150., 150.]], np.float32))
     with pytest.raises(mifwi.MifwiError):
         plan.tti_forward(np.zeros((10, 1), np.float32))
+    with pytest.raises(mifwi.MifwiError):
+        plan.tti_born(np.zeros((10, 1), np.float32), np.zeros((30, 30), np.float32))
+    with pytest.raises(mifwi.MifwiError):
+        plan.tti_gradient(np.zeros((1, 10, 1), np.float32))
+    z = np.zeros((30, 30), np.float32)
+    plan.tti_set_model(z, z, z)
+    with pytest.raises(mifwi.MifwiError):                  # more shots than the plan holds
+        plan.tti_forward(np.zeros((10, 1), np.float32), nshots=2)
+    with pytest.raises(mifwi.MifwiError) as e:             # no saved fields yet
+        plan.tti_gradient(np.zeros((1, 10, 1), np.float32))
+    assert e.value.code == -4
+    with pytest.raises(mifwi.MifwiError):                  # saved TTI fields are not readable before a saving run
+        plan.read_wavefield(7)
+    plan.tti_forward(np.zeros((10, 1), np.float32), save=True)
+    assert not plan.read_wavefield(8).any()
+    assert not plan.tti_gradient(np.zeros((1, 10, 1), np.float32)).any()
+    plan.close()
+    plan = mifwi.Plan((30, 30), (10., 10.), (0., 0.), 4, 10, 1.0, 1, 1, flags=mifwi.FLAG_FREE_SURFACE)
+    with pytest.raises(mifwi.MifwiError):                  # no TTI with a free surface
+        plan.tti_set_model(z, z, z)
     plan.close()
     plan = mifwi.Plan((30, 30), (10., 10.), (0., 0.), 6, 10, 1.0, 1, 1)
     z = np.zeros((30, 30), np.float32)
