@@ -330,6 +330,9 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if use_dist:
+        # communicator set-up is lazy (first collective); keep it out of the timed region even with --warmup 0
+        dist.all_reduce(torch.zeros(1, dtype=torch.float64, device=dev))
     for _ in range(args.warmup):
         step()
     barrier()

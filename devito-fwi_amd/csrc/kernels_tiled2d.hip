@@ -104,15 +104,17 @@ __device__ inline void st4_half_stream_at(char *base, unsigned off, float4 v, fl
     __builtin_nontemporal_store(t, reinterpret_cast<vuint2_2d *>(base + (off >> 1)));
 }
 
-// MODE 0: plain propagation, 1: gradient, 2: scattered field of Born modelling.
+// MODE 0: plain propagation, 1: gradient, 2: scattered field of Born modelling, 4: gradient of two steps
+// (a.pair): the step before ran as MODE 0 and its terms are added here, which halves the read-modify-write
+// traffic of the accumulators.
 template <int R, int TX, int TZ, int MODE>
 // Register budget of the gradient variant: 128 VGPRs, i.e. four blocks per CU (unconstrained it takes
 // 136 and three).  A batch of 8 shots is ~3.1 tiles per CU, so with three resident blocks the last
 // tiles of a launch wait for a free slot: 7.6 -> 6.6 us per step.  The plain variant fits anyway and
 // schedules better without the bound.
-__global__ __launch_bounds__(TX *TZ / 4, MODE == 1 ? 4 : 1) void step2d_kernel(Step2DArgs a)
+__global__ __launch_bounds__(TX *TZ / 4, (MODE == 1 || MODE == 4) ? 4 : 1) void step2d_kernel(Step2DArgs a)
 {
-    constexpr bool GRAD = (MODE == 1), BORN = (MODE == 2);
+    constexpr bool GRAD = (MODE == 1 || MODE == 4), PAIR = (MODE == 4), BORN = (MODE == 2);
     constexpr int RZ = (R + 3) / 4 * 4;          // z halo in LDS, multiple of 4
     constexpr int ROWF4 = (TZ + 2 * RZ) / 4;     // float4 per staged row
     constexpr int P = tile2d_lds_pitch(TZ, R);   // LDS row pitch in floats
@@ -170,7 +172,7 @@ __global__ __launch_bounds__(TX *TZ / 4, MODE == 1 ? 4 : 1) void step2d_kernel(S
             stage[i] = ld4_at(curb, (unsigned)((int)a.off0 + gx * (int)a.s1 + (z0 - RZ + 4 * q)) * 4u);
     }
     float4 m4 = make_float4(1.f, 1.f, 1.f, 1.f), e4 = make_float4(0.f, 0.f, 0.f, 0.f), o4 = e4;
-    float4 u04 = e4, up4 = e4, gv = e4, iv = e4;
+    float4 u04 = e4, up4 = e4, gv = e4, iv = e4, po4 = e4;
     float4 bn4 = e4, bc4 = e4, bo4 = e4, bd4 = e4;
     const long gs = (long)shot * a.g_shot_stride + p;
     if (live) {
@@ -182,12 +184,16 @@ __global__ __launch_bounds__(TX *TZ / 4, MODE == 1 ? 4 : 1) void step2d_kernel(S
                 const float inv = 1.0f / a.save_scale[shot];
                 const long hs = (long)shot * a.u_shot_stride * 2;
                 u04 = ld4_half_stream_at(reinterpret_cast<const char *>(a.uc) + hs, pb, inv);
-                if (a.first && a.illum) up4 = ld4_half_stream_at(reinterpret_cast<const char *>(a.up) + hs, pb, inv);
+                if (PAIR || (a.first && a.illum))
+                    up4 = ld4_half_stream_at(reinterpret_cast<const char *>(a.up) + hs, pb, inv);
             } else {
                 u04 = ld4_stream_at(reinterpret_cast<const char *>(a.uc + (long)shot * a.u_shot_stride), pb);
-                if (a.first && a.illum)
+                if (PAIR)
+                    up4 = ld4_stream_at(reinterpret_cast<const char *>(a.up + (long)shot * a.u_shot_stride), pb);
+                else if (a.first && a.illum)
                     up4 = ld4_at(reinterpret_cast<const char *>(a.up + (long)shot * a.u_shot_stride), pb);
             }
+            if (PAIR) po4 = ld4_at(outb, pb);   // backward level time + 2, about to be overwritten
             gv = ld4_at(reinterpret_cast<const char *>(a.grad + (long)shot * a.g_shot_stride), pb);
             if (a.illum) iv = ld4_at(reinterpret_cast<const char *>(a.illum + (long)shot * a.g_shot_stride), pb);
         }
@@ -310,13 +316,25 @@ __global__ __launch_bounds__(TX *TZ / 4, MODE == 1 ? 4 : 1) void step2d_kernel(S
         if (GRAD) {
             const float u0[4] = {u04.x, u04.y, u04.z, u04.w}, up[4] = {up4.x, up4.y, up4.z, up4.w};
             float g[4] = {gv.x, gv.y, gv.z, gv.w}, il[4] = {iv.x, iv.y, iv.z, iv.w};
+            if (PAIR) {
+                // terms of the step before (time + 1), added first: the sums keep their order in time
+                const float po[4] = {po4.x, po4.y, po4.z, po4.w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    g[i] = grad_accumulate(g[i], po[i], oo[i], uc[i], up[i], a.inv_dt2);
+                    il[i] = illum_accumulate(il[i], up[i]);
+                }
+            }
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 // zero-lag correlation, summed by parts over time: the second time difference is taken
                 // of the backward field (all three levels are in registers here) instead of the saved
                 // forward field, so one saved level is read per step instead of three
-                g[i] += -((oo[i] - 2.0f * uc[i] + res[i]) * a.inv_dt2) * u0[i];
-                il[i] += u0[i] * u0[i] + up[i] * up[i];
+                g[i] = grad_accumulate(g[i], oo[i], uc[i], res[i], u0[i], a.inv_dt2);
+                if (!PAIR && a.first)
+                    il[i] = illum_accumulate(illum_accumulate(il[i], up[i]), u0[i]);   // levels nt-1, nt-2
+                else
+                    il[i] = illum_accumulate(il[i], u0[i]);
             }
             if (full) {
                 st4_at(reinterpret_cast<char *>(a.grad + (long)shot * a.g_shot_stride), pb, make_float4(g[0], g[1], g[2], g[3]));
@@ -337,7 +355,9 @@ __global__ __launch_bounds__(TX *TZ / 4, MODE == 1 ? 4 : 1) void step2d_kernel(S
 template <int R, int TX, int TZ>
 static int launch_rt(const Plan &p, const Step2DArgs &a, int nblocks, hipStream_t stream)
 {
-    if (a.um)
+    if (a.um && a.pair)
+        hipLaunchKernelGGL((step2d_kernel<R, TX, TZ, 4>), dim3(nblocks), dim3(TX * TZ / 4), 0, stream, a);
+    else if (a.um)
         hipLaunchKernelGGL((step2d_kernel<R, TX, TZ, 1>), dim3(nblocks), dim3(TX * TZ / 4), 0, stream, a);
     else if (a.b_un)
         hipLaunchKernelGGL((step2d_kernel<R, TX, TZ, 2>), dim3(nblocks), dim3(TX * TZ / 4), 0, stream, a);

@@ -453,6 +453,7 @@ static int create(const mifwi_config *cfg, mifwi_plan **out)
         delete p;
         return fail(MIFWI_EINVAL, "grid too large for 32-bit sparse offsets");
     }
+    if (const char *env = getenv("MIFWI_PAIR_GRAD")) p->pair_grad = atoi(env);  // tuning experiments
     if (cfg->ndim == 2 && cfg->dtype == MIFWI_F32 && !(cfg->flags & (MIFWI_FLAG_GENERIC | MIFWI_FLAG_OT4))) {
         // tiled fast path: pick the tile shape that wastes fewer threads on this grid
         const int n1 = p->L.n[1], n2 = p->L.n[2];
@@ -864,10 +865,12 @@ static int forward_step(Plan &p, const LoopCtx<T> &c, const T *cur, const T *old
 // One backward step: out = step(cur, old) + injected adjoint source of `time`.  With u0 != null
 // the gradient (and illumination) accumulators are updated from the saved forward levels
 // um/u0/up = u[time-1], u[time], u[time+1]; without, the field is sampled at the source positions.
+// pair_role (tiled 2-D kernel only) 1: plain step of a gradient loop whose terms the next step adds
+// (u0 == null, nothing sampled); 2: that next step.
 template <typename T>
 static int backward_step(Plan &p, const LoopCtx<T> &c, const T *cur, const T *old, T *out, long shot_stride, int time,
                          const T *um, const T *u0, const T *up, long u_stride, bool with_illum, bool first,
-                         int &launches)
+                         int &launches, int pair_role = 0)
 {
     int rc;
     const bool with_grad = (u0 != nullptr);
@@ -875,7 +878,8 @@ static int backward_step(Plan &p, const LoopCtx<T> &c, const T *cur, const T *ol
         Step2DArgs a = c.a2;
         a.shot_stride = shot_stride;
         set_inject(a, p.rec, p);
-        if (!with_grad) set_interp(a, p.src, p.d_srca);
+        if (!with_grad && pair_role != 1) set_interp(a, p.src, p.d_srca);
+        a.pair = (pair_role == 2);
         a.cur = (const float *)cur, a.old = (const float *)old, a.out = (float *)out, a.time = time;
         if (with_grad) {
             a.um = (const float *)um, a.uc = (const float *)u0, a.up = (const float *)up;
@@ -1030,6 +1034,7 @@ static int prepare_save(Plan &p)
     p.save_f16 = false;   // checkpoints restart the propagation and stay float32
     const int nsteps = nt - 2;
     p.ck_K = std::max(2, (int)std::ceil(std::sqrt(2.0 * nsteps)));
+    p.ck_K += p.ck_K & 1;   // even: segments then start at odd times and never split a pair of gradient steps
     p.ck_nseg = (nsteps + p.ck_K - 1) / p.ck_K;
     const size_t need = level * (2 * (size_t)p.ck_nseg + p.ck_K + 2);
     if ((double)need > 0.95 * (double)free_b)
@@ -1146,6 +1151,16 @@ static int run_backward(Plan &p, int nshots, bool with_grad, bool with_illum)
     const LoopCtx<T> fctx = make_ctx<T>(p, nshots, false);
     auto lvl = [&](int t) { return base + (long)((t + 3) % 3) * L.field; };
     const bool ckpt = with_grad && p.ck_K > 0;
+    // Tiled 2-D kernel: two gradient steps share one update of the accumulators.  The step at an even
+    // time runs as a plain propagation (role 1) and the following one, at the odd time below it, adds both
+    // steps' terms (role 2).  Roles depend on the time index alone, so a checkpointed loop (segments start
+    // at odd times) runs the same kernel at every step as the fully saved one.
+    const bool pair_grad = with_grad && p.kind == 1 && p.pair_grad;
+    auto pair_role = [&](int time) {
+        if (!pair_grad) return 0;
+        if (time % 2 == 0) return (time != nt - 2 && time >= 2) ? 1 : 0;
+        return (time + 1 < nt - 2) ? 2 : 0;
+    };
     auto enqueue = [&](int &launches) -> int {
         int r;
         if (!ckpt) {
@@ -1156,9 +1171,11 @@ static int run_backward(Plan &p, int nshots, bool with_grad, bool with_illum)
             auto saved_level = [&](int t) { return (const T *)(sv + (size_t)t * sv_lstride * es); };
             for (int time = nt - 2; time >= 1; --time) {
                 const T *u0 = with_grad ? saved_level(time) : nullptr;
+                const int role = pair_role(time);
+                if (role == 1) u0 = nullptr;
                 if ((r = backward_step<T>(p, ctx, lvl(time), lvl(time + 1), lvl(time - 1), shot_stride, time,
                                           u0 ? saved_level(time - 1) : nullptr, u0, u0 ? saved_level(time + 1) : nullptr,
-                                          sv_stride, with_illum, time == nt - 2, launches)))
+                                          sv_stride, with_illum, time == nt - 2, launches, role)))
                     return r;
             }
             return MIFWI_OK;
@@ -1179,9 +1196,10 @@ static int run_backward(Plan &p, int nshots, bool with_grad, bool with_illum)
             }
             for (int time = t1; time >= t0; --time) {
                 const T *u0 = seg + (long)(time - t0 + 1) * L.field;
+                const int role = pair_role(time);
                 if ((r = backward_step<T>(p, ctx, lvl(time), lvl(time + 1), lvl(time - 1), shot_stride, time,
-                                          u0 - L.field, u0, u0 + L.field, seg_stride, with_illum, time == nt - 2,
-                                          launches)))
+                                          u0 - L.field, role == 1 ? nullptr : u0, u0 + L.field, seg_stride, with_illum,
+                                          time == nt - 2, launches, role)))
                     return r;
             }
         }

@@ -156,6 +156,7 @@ struct Plan {
     int nchunk_env = 0;
     unsigned char *eta_zero = nullptr;  // 2.5-D kernel: [tile][n0] flags of sponge-free patches
     int vec3d = 0;  // points per thread of the 2.5-D kernel: 0 = by stencil radius, else 2 or 4
+    int pair_grad = 1;  // gradient loops update the accumulators every second step (tiled 2-D kernel)
 
     // captured time loops: (loop kind, nshots, variant a, variant b, group) -> executable graph + launches
     std::map<std::tuple<int, int, int, int, int>, std::pair<hipGraphExec_t, int>> graphs;
@@ -330,6 +331,10 @@ struct Step2DArgs {
     float *grad, *illum;
     long g_shot_stride;
     int first;
+    // pair != 0: this launch also adds the gradient / illumination terms of the step before it (time + 1),
+    // which ran as a plain propagation: its three backward levels are `out`'s old content, `old` and
+    // `cur`, and `up` is the saved forward level time + 1
+    int pair;
     // injection (slot_count == nullptr: none): per tile the cells it owns, and their precomputed
     // terms winj[shot][time][slot_base[tile] + j]
     const int32_t *slot_count, *slot_local, *slot_base;
@@ -401,6 +406,24 @@ int launch_step3d(const Plan &p, const Step3DArgs &a, hipStream_t stream);
 int launch_eta_zero(const Plan &p, unsigned char *flags);
 int step3d_blocks_per_cu(int R, bool grad);
 
+
+// ---- gradient and illumination terms with pinned rounding ----------------------------------------
+// g - ((va - 2 vb + vc) / dt^2) u and il + u^2.  Every gradient kernel forms them through these two
+// functions, so a step's term has the same bits whether it is added by the launch that advances the
+// backward field or, deferred, by the next one.
+__device__ inline float grad_accumulate(float g, float va, float vb, float vc, float u, float inv_dt2)
+{
+#pragma clang fp contract(off)
+    const float d = __builtin_fmaf(-2.0f, vb, va) + vc;
+    const float s = d * inv_dt2;
+    return __builtin_fmaf(-s, u, g);
+}
+__device__ inline float illum_accumulate(float il, float u)
+{
+#pragma clang fp contract(off)
+    const float s = u * u;
+    return il + s;
+}
 
 // ---- half-precision storage of saved levels -----------------------------------------------------
 // value -> half(value * scale), saturating at the largest finite half instead of overflowing to inf
