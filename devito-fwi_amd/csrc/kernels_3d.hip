@@ -123,11 +123,12 @@ __device__ inline void lds_stv(float *p, const float (&d)[V])
 #define MIFWI_3D_GRAD_WAVES 2
 #endif
 // MODE 0: plain propagation, 1: gradient, 2: scattered field of Born modelling, 3: plain propagation that
-// also streams a half-precision copy of the new level into the saved array.
+// also streams a half-precision copy of the new level into the saved array, 4: gradient of two steps
+// (a.pair: the step before ran as MODE 0 and its terms are added here, see Step2DArgs::pair).
 template <int R, int TY, int TZ, int V, int MODE, bool ISO>
-__global__ __launch_bounds__(TY *TZ / V, (MODE == 1 || MODE == 2 ? MIFWI_3D_GRAD_WAVES : 3) * (TY * TZ / V) / 256) void step3d_kernel(Step3DArgs a)
+__global__ __launch_bounds__(TY *TZ / V, (MODE == 1 || MODE == 2 || MODE == 4 ? MIFWI_3D_GRAD_WAVES : 3) * (TY * TZ / V) / 256) void step3d_kernel(Step3DArgs a)
 {
-    constexpr bool GRAD = (MODE == 1), BORN = (MODE == 2);
+    constexpr bool GRAD = (MODE == 1 || MODE == 4), PAIR = (MODE == 4), BORN = (MODE == 2);
     constexpr int NT = TY * TZ / V;                     // threads per block
     constexpr int RZ = (R + 3) / 4 * 4;
     constexpr int RZ4 = RZ / 4;
@@ -302,11 +303,11 @@ __global__ __launch_bounds__(TY *TZ / V, (MODE == 1 || MODE == 2 ? MIFWI_3D_GRAD
                 ldv_stream<V>(reinterpret_cast<const char *>(a.b_dm) + (long)x * sb, col, bd);
             }
         }
-        float u0[V], up[V], g[V], il[V];
+        float u0[V], up[V], g[V], il[V], po[V];
         char *gradb = nullptr, *illumb = nullptr;
         if (GRAD) {
 #pragma unroll
-            for (int i = 0; i < V; ++i) u0[i] = up[i] = g[i] = il[i] = 0.f;
+            for (int i = 0; i < V; ++i) u0[i] = up[i] = g[i] = il[i] = po[i] = 0.f;
             gradb = reinterpret_cast<char *>(a.grad + (long)shot * a.g_shot_stride) + (long)x * sb;
             illumb = a.illum ? reinterpret_cast<char *>(a.illum + (long)shot * a.g_shot_stride) + (long)x * sb : nullptr;
             if (live) {
@@ -314,11 +315,13 @@ __global__ __launch_bounds__(TY *TZ / V, (MODE == 1 || MODE == 2 ? MIFWI_3D_GRAD
                 if (a.save_scale) {   // half-precision saved levels (uniform branch)
                     const float inv = 1.0f / a.save_scale[shot];
                     ldv_half_stream<V>(reinterpret_cast<const char *>(a.uc) + (us >> 1), col, inv, u0);
-                    if (a.first && illumb) ldv_half_stream<V>(reinterpret_cast<const char *>(a.up) + (us >> 1), col, inv, up);
+                    if (PAIR || (a.first && illumb))
+                        ldv_half_stream<V>(reinterpret_cast<const char *>(a.up) + (us >> 1), col, inv, up);
                 } else {
                     ldv_stream<V>(reinterpret_cast<const char *>(a.uc) + us, col, u0);
-                    if (a.first && illumb) ldv_stream<V>(reinterpret_cast<const char *>(a.up) + us, col, up);
+                    if (PAIR || (a.first && illumb)) ldv_stream<V>(reinterpret_cast<const char *>(a.up) + us, col, up);
                 }
+                if (PAIR) ldv_stream<V>(out + (long)x * sb, col, po);   // backward level time + 2, about to be overwritten
                 ldv_stream<V>(gradb, col, g);
                 if (illumb) ldv_stream<V>(illumb, col, il);
             }
@@ -414,12 +417,23 @@ __global__ __launch_bounds__(TY *TZ / V, (MODE == 1 || MODE == 2 ? MIFWI_3D_GRAD
                 }
             }
             if (GRAD) {
+                if (PAIR) {
+                    // terms of the step before (time + 1), added first: the sums keep their order in time
+#pragma unroll
+                    for (int i = 0; i < V; ++i) {
+                        g[i] = grad_accumulate(g[i], po[i], oo[i], uc[i], up[i], a.inv_dt2);
+                        il[i] = illum_accumulate(il[i], up[i]);
+                    }
+                }
 #pragma unroll
                 for (int i = 0; i < V; ++i) {
                     // correlation summed by parts over time (see kernels_tiled2d.hip): second time
                     // difference of the backward field, one saved forward level per step
-                    g[i] += -((oo[i] - 2.0f * uc[i] + res[i]) * a.inv_dt2) * u0[i];
-                    il[i] += u0[i] * u0[i] + up[i] * up[i];
+                    g[i] = grad_accumulate(g[i], oo[i], uc[i], res[i], u0[i], a.inv_dt2);
+                    if (!PAIR && a.first)
+                        il[i] = illum_accumulate(illum_accumulate(il[i], up[i]), u0[i]);   // levels nt-1, nt-2
+                    else
+                        il[i] = illum_accumulate(il[i], u0[i]);
                 }
                 if (full) {
                     stv_stream<V>(gradb, col, g);
@@ -470,7 +484,9 @@ static int launch_r3v(const Plan &p, const Step3DArgs &a, hipStream_t stream)
     constexpr int NT = 16 * 64 / V;
     const int nitp = a.pt_idx ? (((a.itp_npoint + NT - 1) / NT) * a.nshots + 7) / 8 * 8 : 0;
     const int nblocks = (a.nwork + 7) / 8 * 8 + nitp;
-    if (a.um)
+    if (a.um && a.pair)
+        hipLaunchKernelGGL((step3d_kernel<R, 16, 64, V, 4, ISO>), dim3(nblocks), dim3(NT), 0, stream, a);
+    else if (a.um)
         hipLaunchKernelGGL((step3d_kernel<R, 16, 64, V, 1, ISO>), dim3(nblocks), dim3(NT), 0, stream, a);
     else if (a.b_un)   // always four points per thread
         hipLaunchKernelGGL((step3d_kernel<R, 16, 64, 4, 2, ISO>), dim3((a.nwork + 7) / 8 * 8 +

@@ -865,7 +865,7 @@ static int forward_step(Plan &p, const LoopCtx<T> &c, const T *cur, const T *old
 // One backward step: out = step(cur, old) + injected adjoint source of `time`.  With u0 != null
 // the gradient (and illumination) accumulators are updated from the saved forward levels
 // um/u0/up = u[time-1], u[time], u[time+1]; without, the field is sampled at the source positions.
-// pair_role (tiled 2-D kernel only) 1: plain step of a gradient loop whose terms the next step adds
+// pair_role (tiled kernels only) 1: plain step of a gradient loop whose terms the next step adds
 // (u0 == null, nothing sampled); 2: that next step.
 template <typename T>
 static int backward_step(Plan &p, const LoopCtx<T> &c, const T *cur, const T *old, T *out, long shot_stride, int time,
@@ -898,7 +898,8 @@ static int backward_step(Plan &p, const LoopCtx<T> &c, const T *cur, const T *ol
         Step3DArgs a = c.a3;
         a.shot_stride = shot_stride;
         set_inject3(a, p.rec, p);
-        if (!with_grad) set_interp3(a, p.src, p.d_srca);
+        if (!with_grad && pair_role != 1) set_interp3(a, p.src, p.d_srca);
+        a.pair = (pair_role == 2);
         a.cur = (const float *)cur, a.old = (const float *)old, a.out = (float *)out, a.time = time;
         if (with_grad) {
             a.um = (const float *)um, a.uc = (const float *)u0, a.up = (const float *)up;
@@ -1151,11 +1152,14 @@ static int run_backward(Plan &p, int nshots, bool with_grad, bool with_illum)
     const LoopCtx<T> fctx = make_ctx<T>(p, nshots, false);
     auto lvl = [&](int t) { return base + (long)((t + 3) % 3) * L.field; };
     const bool ckpt = with_grad && p.ck_K > 0;
-    // Tiled 2-D kernel: two gradient steps share one update of the accumulators.  The step at an even
+    // Tiled kernels: two gradient steps share one update of the accumulators.  The step at an even
     // time runs as a plain propagation (role 1) and the following one, at the odd time below it, adds both
     // steps' terms (role 2).  Roles depend on the time index alone, so a checkpointed loop (segments start
     // at odd times) runs the same kernel at every step as the fully saved one.
-    const bool pair_grad = with_grad && p.kind == 1 && p.pair_grad;
+    // Measured on 592^3 at order 8: with half-precision saved levels the backward loop takes 615 instead
+    // of 670 ms, with float levels (checkpointed) 637 instead of 596 ms, so the 2.5-D kernel pairs only in
+    // the first case (pair_grad == 2 forces it).
+    const bool pair_grad = with_grad && p.pair_grad && (p.kind == 1 || (p.kind == 2 && (p.save_f16 || p.pair_grad == 2)));
     auto pair_role = [&](int time) {
         if (!pair_grad) return 0;
         if (time % 2 == 0) return (time != nt - 2 && time >= 2) ? 1 : 0;
@@ -1173,7 +1177,7 @@ static int run_backward(Plan &p, int nshots, bool with_grad, bool with_illum)
                 const T *u0 = with_grad ? saved_level(time) : nullptr;
                 const int role = pair_role(time);
                 if (role == 1) u0 = nullptr;
-                if ((r = backward_step<T>(p, ctx, lvl(time), lvl(time + 1), lvl(time - 1), shot_stride, time,
+                if ((r = backward_step<T>(p, role == 1 ? fctx : ctx, lvl(time), lvl(time + 1), lvl(time - 1), shot_stride, time,
                                           u0 ? saved_level(time - 1) : nullptr, u0, u0 ? saved_level(time + 1) : nullptr,
                                           sv_stride, with_illum, time == nt - 2, launches, role)))
                     return r;
@@ -1197,7 +1201,7 @@ static int run_backward(Plan &p, int nshots, bool with_grad, bool with_illum)
             for (int time = t1; time >= t0; --time) {
                 const T *u0 = seg + (long)(time - t0 + 1) * L.field;
                 const int role = pair_role(time);
-                if ((r = backward_step<T>(p, ctx, lvl(time), lvl(time + 1), lvl(time - 1), shot_stride, time,
+                if ((r = backward_step<T>(p, role == 1 ? fctx : ctx, lvl(time), lvl(time + 1), lvl(time - 1), shot_stride, time,
                                           u0 - L.field, role == 1 ? nullptr : u0, u0 + L.field, seg_stride, with_illum,
                                           time == nt - 2, launches, role)))
                     return r;

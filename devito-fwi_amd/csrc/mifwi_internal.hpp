@@ -156,7 +156,7 @@ struct Plan {
     int nchunk_env = 0;
     unsigned char *eta_zero = nullptr;  // 2.5-D kernel: [tile][n0] flags of sponge-free patches
     int vec3d = 0;  // points per thread of the 2.5-D kernel: 0 = by stencil radius, else 2 or 4
-    int pair_grad = 1;  // gradient loops update the accumulators every second step (tiled 2-D kernel)
+    int pair_grad = 1;  // gradient loops update the accumulators every second step (tiled kernels)
 
     // captured time loops: (loop kind, nshots, variant a, variant b, group) -> executable graph + launches
     std::map<std::tuple<int, int, int, int, int>, std::pair<hipGraphExec_t, int>> graphs;
@@ -379,6 +379,7 @@ struct Step3DArgs {
     float *grad, *illum;
     long g_shot_stride;
     int first;
+    int pair;   // see Step2DArgs::pair
     // injection (cell_ptr == nullptr: none): cells ordered by (tile, plane) and their precomputed
     // terms winj[shot][time][position]
     const int32_t *cell_ptr, *cell_local;
