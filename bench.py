@@ -372,7 +372,9 @@ def main():
                 "avg_launch_us": bwd_ms * 1e3 / max(1, bwd_launches),
                 "bytes_per_launch": g_bytes_loop / max(1, bwd_launches),
                 "timing": "HIP events around the backward time loop on the plan's stream / launches "
-                          "(includes inter-kernel gaps)"}
+                          "(includes inter-kernel gaps)",
+                "schedule": "the loop alternates a plain step (step2d_kernel mode 0) and a step that adds the "
+                            "gradient terms of both (mode 4); launch time, bytes and traffic are means over the loop"}
     roofline_fwd = {"bound": "hbm", "achieved": f_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": f_ach / HBM_PEAK_GBS, "traffic": pmc_traffic(st["fwd_kernel"]), "kernel": st["fwd_kernel"],
                     "launches_per_loop": fwd_launches, "avg_launch_us": fwd_ms * 1e3 / max(1, fwd_launches)}
