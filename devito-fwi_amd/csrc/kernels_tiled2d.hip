@@ -281,27 +281,34 @@ __global__ __launch_bounds__(TX *TZ / 4, (MODE == 1 || MODE == 4) ? 4 : 1) void 
             for (int i = 0; i < 4; ++i)
                 if (z + i < a.n2) a.out[ps + i] = res[i];
         }
-        if (a.copy && a.save_scale) {
-            // half-precision saved level
-            const float sc = a.save_scale[shot];
-            char *cb = reinterpret_cast<char *>(a.copy) + (long)shot * a.copy_shot_stride * 2;
-            if (full) {
-                st4_half_stream_at(cb, pb, make_float4(res[0], res[1], res[2], res[3]), sc);
-            } else {
-                __half *ch = reinterpret_cast<__half *>(cb) + p;
-                for (int i = 0; i < 4; ++i)
-                    if (z + i < a.n2) ch[i] = __float2half_rn(fminf(fmaxf(res[i] * sc, -65504.0f), 65504.0f));
-            }
-        } else if (a.copy) {
-            // the saved forward level is a write-only stream here: the time loop itself runs on the
-            // three rotating levels, which stay cache resident
-            float *cp = a.copy + (long)shot * a.copy_shot_stride + p;
-            if (full) {
-                st4_stream_at(reinterpret_cast<char *>(a.copy + (long)shot * a.copy_shot_stride), pb,
-                              make_float4(res[0], res[1], res[2], res[3]));
-            } else {
-                for (int i = 0; i < 4; ++i)
-                    if (z + i < a.n2) cp[i] = res[i];
+        if (a.copy) {
+            // the saved forward levels are write-only streams here: the time loop itself runs on the three
+            // rotating levels, which stay cache resident.  `copy_prev` takes the level just read.
+            float *dsts[2] = {a.copy, a.copy_prev};
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                if (!dsts[c]) continue;   // block-uniform
+                const float *val = c ? uc : res;
+                if (a.save_scale) {
+                    const float sc = a.save_scale[shot];
+                    char *cb = reinterpret_cast<char *>(dsts[c]) + (long)shot * a.copy_shot_stride * 2;
+                    if (full) {
+                        st4_half_stream_at(cb, pb, make_float4(val[0], val[1], val[2], val[3]), sc);
+                    } else {
+                        __half *ch = reinterpret_cast<__half *>(cb) + p;
+                        for (int i = 0; i < 4; ++i)
+                            if (z + i < a.n2) ch[i] = __float2half_rn(fminf(fmaxf(val[i] * sc, -65504.0f), 65504.0f));
+                    }
+                } else {
+                    float *cp = dsts[c] + (long)shot * a.copy_shot_stride + p;
+                    if (full) {
+                        st4_stream_at(reinterpret_cast<char *>(dsts[c] + (long)shot * a.copy_shot_stride), pb,
+                                      make_float4(val[0], val[1], val[2], val[3]));
+                    } else {
+                        for (int i = 0; i < 4; ++i)
+                            if (z + i < a.n2) cp[i] = val[i];
+                    }
+                }
             }
         }
         if (a.fs && z <= R) {

@@ -454,6 +454,7 @@ static int create(const mifwi_config *cfg, mifwi_plan **out)
         return fail(MIFWI_EINVAL, "grid too large for 32-bit sparse offsets");
     }
     if (const char *env = getenv("MIFWI_PAIR_GRAD")) p->pair_grad = atoi(env);  // tuning experiments
+    if (const char *env = getenv("MIFWI_PAIR_SAVE")) p->pair_save = atoi(env);  // tuning experiments
     if (cfg->ndim == 2 && cfg->dtype == MIFWI_F32 && !(cfg->flags & (MIFWI_FLAG_GENERIC | MIFWI_FLAG_OT4))) {
         // tiled fast path: pick the tile shape that wastes fewer threads on this grid
         const int n1 = p->L.n[1], n2 = p->L.n[2];
@@ -790,7 +791,7 @@ struct BornTerm {
 template <typename T>
 static int forward_step(Plan &p, const LoopCtx<T> &c, const T *cur, const T *old, T *out, long shot_stride, int time,
                         bool interp, int &launches, bool inject = true, T *copy = nullptr, long copy_stride = 0,
-                        const BornTerm<T> *born = nullptr)
+                        const BornTerm<T> *born = nullptr, T *copy_prev = nullptr)
 {
     int rc;
     if (p.kind == 1) {
@@ -799,7 +800,7 @@ static int forward_step(Plan &p, const LoopCtx<T> &c, const T *cur, const T *old
         if (inject) set_inject(a, p.src, p);
         if (interp) set_interp(a, p.rec, p.d_rec);
         a.cur = (const float *)cur, a.old = (const float *)old, a.out = (float *)out, a.time = time;
-        a.copy = (float *)copy, a.copy_shot_stride = copy_stride;
+        a.copy = (float *)copy, a.copy_shot_stride = copy_stride, a.copy_prev = (float *)copy_prev;
         if (copy && p.save_f16) a.save_scale = (const float *)p.d_save_scale;
         if (born) {
             a.b_un = (const float *)born->un, a.b_uc = (const float *)born->uc, a.b_uo = (const float *)born->uo;
@@ -1101,9 +1102,16 @@ static int run_forward(Plan &p, int nshots, int save)
                 if ((r = copy_levels<T>(p, dst, cstride, lvl(time - 1), shot_stride, 1, nshots))) return r;
                 if ((r = copy_levels<T>(p, dst + L.field, cstride, lvl(time), shot_stride, 1, nshots))) return r;
             }
-            T *copy = copy_save ? (T *)((char *)p.saved + (size_t)(time + 1) * sv_lstride * es) : nullptr;
+            auto saved_at = [&](int level) { return (T *)((char *)p.saved + (size_t)level * sv_lstride * es); };
+            T *copy = copy_save ? saved_at(time + 1) : nullptr, *copy_prev = nullptr;
+            if (copy_save && p.kind == 1 && p.pair_save) {
+                // steps at even times write the saved levels time and time + 1, the others none (the last
+                // step always writes its own)
+                if (time % 2 == 0) copy_prev = saved_at(time);
+                else if (time != nt - 2) copy = nullptr;
+            }
             int r = forward_step<T>(p, ctx, lvl(time), lvl(time - 1), lvl(time + 1), shot_stride, time, true, launches,
-                                    true, copy, L.field);
+                                    true, copy, L.field, nullptr, copy_prev);
             if (r) return r;
         }
         return MIFWI_OK;

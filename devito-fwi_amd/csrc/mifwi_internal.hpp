@@ -156,6 +156,7 @@ struct Plan {
     int nchunk_env = 0;
     unsigned char *eta_zero = nullptr;  // 2.5-D kernel: [tile][n0] flags of sponge-free patches
     int vec3d = 0;  // points per thread of the 2.5-D kernel: 0 = by stencil radius, else 2 or 4
+    int pair_save = 1;  // saving forward loops of the tiled 2-D kernel write two saved levels every second step
     int pair_grad = 1;  // gradient loops update the accumulators every second step (tiled kernels)
 
     // captured time loops: (loop kind, nshots, variant a, variant b, group) -> executable graph + launches
@@ -351,7 +352,10 @@ struct Step2DArgs {
     // second, streamed copy of `out` (the saved forward level), or null
     float *copy;
     long copy_shot_stride;
-    // save_scale != nullptr: `copy` and um/uc/up are half precision, value * save_scale[shot]; their
+    // streamed copy of `cur` into the saved level before it, or null: every second step of a saving loop
+    // writes two saved levels and the steps between write none
+    float *copy_prev;
+    // save_scale != nullptr: `copy`, `copy_prev` and um/uc/up are half precision, value * save_scale[shot]; their
     // strides still count elements
     const float *save_scale;
     // Born source term (b_un == nullptr: none): the field being advanced is the scattered one and
