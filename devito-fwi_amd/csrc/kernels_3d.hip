@@ -122,6 +122,9 @@ __device__ inline void lds_stv(float *p, const float (&d)[V])
 #ifndef MIFWI_3D_GRAD_WAVES
 #define MIFWI_3D_GRAD_WAVES 2
 #endif
+#ifndef MIFWI_3D_PF_MAXR
+#define MIFWI_3D_PF_MAXR 4
+#endif
 // MODE 0: plain propagation, 1: gradient, 2: scattered field of Born modelling, 3: plain propagation that
 // also streams a half-precision copy of the new level into the saved array, 4: gradient of two steps
 // (a.pair: the step before ran as MODE 0 and its terms are added here, see Step2DArgs::pair).
@@ -129,6 +132,9 @@ template <int R, int TY, int TZ, int V, int MODE, bool ISO>
 __global__ __launch_bounds__(TY *TZ / V, (MODE == 1 || MODE == 2 || MODE == 4 ? MIFWI_3D_GRAD_WAVES : 3) * (TY * TZ / V) / 256) void step3d_kernel(Step3DArgs a)
 {
     constexpr bool GRAD = (MODE == 1 || MODE == 4), PAIR = (MODE == 4), BORN = (MODE == 2);
+    // PF: the coefficient and old-level loads of plane x + 1 are issued during plane x (one more plane of
+    // lead for 12 more registers); only where the register budget has the room
+    constexpr bool PF = (R <= MIFWI_3D_PF_MAXR) && MODE == 0;
     constexpr int NT = TY * TZ / V;                     // threads per block
     constexpr int RZ = (R + 3) / 4 * 4;
     constexpr int RZ4 = RZ / 4;
@@ -240,6 +246,17 @@ __global__ __launch_bounds__(TY *TZ / V, (MODE == 1 || MODE == 2 || MODE == 4 ? 
         if (h_ok[i]) ldv<4>(cur + (long)xa * sb, h_glb[i], hv[i]);
     }
 
+    float mm_n[V], ee_n[V], oo_n[V];
+    if (PF) {
+#pragma unroll
+        for (int i = 0; i < V; ++i) mm_n[i] = 1.f, ee_n[i] = 0.f, oo_n[i] = 0.f;
+        if (live) {
+            ldv_stream<V>(mb + (long)xa * sb, col, mm_n);
+            if (!(ezero && ezero[xa] != 0)) ldv_stream<V>(eb + (long)xa * sb, col, ee_n);
+            ldv_stream<V>(old + (long)xa * sb, col, oo_n);
+        }
+    }
+
     int buf = 0;
     for (int x = xa; x < xb; ++x) {
         // advance the queue: plane x+R arrived during the previous plane, x+R+1 is requested now
@@ -257,7 +274,10 @@ __global__ __launch_bounds__(TY *TZ / V, (MODE == 1 || MODE == 2 || MODE == 4 ? 
         for (int i = 0; i < V; ++i) mm[i] = 1.f, ee[i] = 0.f, oo[i] = 0.f;
         // planes of the tile where the sponge is identically zero skip its 4 bytes per point
         const bool eta_is_zero = ezero ? (ezero[x] != 0) : false;   // block-uniform
-        if (live) {
+        if (PF) {
+#pragma unroll
+            for (int i = 0; i < V; ++i) mm[i] = mm_n[i], ee[i] = ee_n[i], oo[i] = oo_n[i];
+        } else if (live) {
             ldv_stream<V>(mb + (long)x * sb, col, mm);
             if (!eta_is_zero) ldv_stream<V>(eb + (long)x * sb, col, ee);
             ldv_stream<V>(old + (long)x * sb, col, oo);
@@ -290,6 +310,15 @@ __global__ __launch_bounds__(TY *TZ / V, (MODE == 1 || MODE == 2 || MODE == 4 ? 
 #pragma unroll
             for (int i = 0; i < NHT; ++i)
                 if (h_ok[i]) ldv<4>(cur + (long)(x + 1) * sb, h_glb[i], hv[i]);
+            if (PF) {
+#pragma unroll
+                for (int i = 0; i < V; ++i) ee_n[i] = 0.f;
+                if (live) {
+                    ldv_stream<V>(mb + (long)(x + 1) * sb, col, mm_n);
+                    if (!(ezero && ezero[x + 1] != 0)) ldv_stream<V>(eb + (long)(x + 1) * sb, col, ee_n);
+                    ldv_stream<V>(old + (long)(x + 1) * sb, col, oo_n);
+                }
+            }
         }
         float bn[V], bc[V], bo[V], bd[V];
         if (BORN) {
