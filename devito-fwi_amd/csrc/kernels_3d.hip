@@ -123,7 +123,7 @@ __device__ inline void lds_stv(float *p, const float (&d)[V])
 #define MIFWI_3D_GRAD_WAVES 2
 #endif
 #ifndef MIFWI_3D_PF_MAXR
-#define MIFWI_3D_PF_MAXR 4
+#define MIFWI_3D_PF_MAXR 5
 #endif
 // MODE 0: plain propagation, 1: gradient, 2: scattered field of Born modelling, 3: plain propagation that
 // also streams a half-precision copy of the new level into the saved array, 4: gradient of two steps
