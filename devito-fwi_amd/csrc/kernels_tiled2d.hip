@@ -6,8 +6,9 @@
 //     read through the stencil (plus a halo of R rows / round_up(R,4) columns) is staged in LDS with
 //     16-byte loads; every thread then produces 4 consecutive z points from ds_read_b128 reads (the
 //     z line once, 2R row neighbours), reads old/m/eta with one aligned 16-byte load each and
-//     stores 16 bytes.  The gradient variant also reads the three saved forward levels and
-//     read-modify-writes grad (and illum).
+//     stores 16 bytes.  The gradient variants also read one saved forward level per step they account
+//     for and read-modify-write grad (and illum); a saving forward step also streams the new level (and,
+//     every second step, the level it read) into the saved array.
 //   * a tile block that owns cells touched by sources/receivers (per-tile slot table built on the
 //     host) forms their injected terms in LDS while its stencil loads are in flight -- one thread per
 //     cell, fixed summation order, no atomics -- and the owning threads add them before storing.
