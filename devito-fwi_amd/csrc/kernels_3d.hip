@@ -283,6 +283,31 @@ __global__ __launch_bounds__(TY *TZ / V, (MODE == 1 || MODE == 2 || MODE == 4 ? 
             ldv_stream<V>(old + (long)x * sb, col, oo);
         }
 
+        // accumulators and saved level(s) of this plane: issued with the coefficient loads, used last
+        float u0[V], up[V], g[V], il[V], po[V];
+        char *gradb = nullptr, *illumb = nullptr;
+        if (GRAD) {
+#pragma unroll
+            for (int i = 0; i < V; ++i) u0[i] = up[i] = g[i] = il[i] = po[i] = 0.f;
+            gradb = reinterpret_cast<char *>(a.grad + (long)shot * a.g_shot_stride) + (long)x * sb;
+            illumb = a.illum ? reinterpret_cast<char *>(a.illum + (long)shot * a.g_shot_stride) + (long)x * sb : nullptr;
+            if (live) {
+                const long us = (long)shot * a.u_shot_stride * 4 + (long)x * sb;
+                if (a.save_scale) {   // half-precision saved levels (uniform branch)
+                    const float inv = 1.0f / a.save_scale[shot];
+                    ldv_half_stream<V>(reinterpret_cast<const char *>(a.uc) + (us >> 1), col, inv, u0);
+                    if (PAIR || (a.first && illumb))
+                        ldv_half_stream<V>(reinterpret_cast<const char *>(a.up) + (us >> 1), col, inv, up);
+                } else {
+                    ldv_stream<V>(reinterpret_cast<const char *>(a.uc) + us, col, u0);
+                    if (PAIR || (a.first && illumb)) ldv_stream<V>(reinterpret_cast<const char *>(a.up) + us, col, up);
+                }
+                if (PAIR) ldv_stream<V>(out + (long)x * sb, col, po);   // backward level time + 2, about to be overwritten
+                ldv_stream<V>(gradb, col, g);
+                if (illumb) ldv_stream<V>(illumb, col, il);
+            }
+        }
+
         // stage plane x: centre from the queue, ring from the registers loaded one plane ago
         float *L = lds[buf];
         lds_stv<V>(&L[(ty + R) * P + RZ + V * tq], q[R]);
@@ -332,30 +357,6 @@ __global__ __launch_bounds__(TY *TZ / V, (MODE == 1 || MODE == 2 || MODE == 4 ? 
                 ldv_stream<V>(reinterpret_cast<const char *>(a.b_dm) + (long)x * sb, col, bd);
             }
         }
-        float u0[V], up[V], g[V], il[V], po[V];
-        char *gradb = nullptr, *illumb = nullptr;
-        if (GRAD) {
-#pragma unroll
-            for (int i = 0; i < V; ++i) u0[i] = up[i] = g[i] = il[i] = po[i] = 0.f;
-            gradb = reinterpret_cast<char *>(a.grad + (long)shot * a.g_shot_stride) + (long)x * sb;
-            illumb = a.illum ? reinterpret_cast<char *>(a.illum + (long)shot * a.g_shot_stride) + (long)x * sb : nullptr;
-            if (live) {
-                const long us = (long)shot * a.u_shot_stride * 4 + (long)x * sb;
-                if (a.save_scale) {   // half-precision saved levels (uniform branch)
-                    const float inv = 1.0f / a.save_scale[shot];
-                    ldv_half_stream<V>(reinterpret_cast<const char *>(a.uc) + (us >> 1), col, inv, u0);
-                    if (PAIR || (a.first && illumb))
-                        ldv_half_stream<V>(reinterpret_cast<const char *>(a.up) + (us >> 1), col, inv, up);
-                } else {
-                    ldv_stream<V>(reinterpret_cast<const char *>(a.uc) + us, col, u0);
-                    if (PAIR || (a.first && illumb)) ldv_stream<V>(reinterpret_cast<const char *>(a.up) + us, col, up);
-                }
-                if (PAIR) ldv_stream<V>(out + (long)x * sb, col, po);   // backward level time + 2, about to be overwritten
-                ldv_stream<V>(gradb, col, g);
-                if (illumb) ldv_stream<V>(illumb, col, il);
-            }
-        }
-
         if (live) {
             const float *ctr = &L[(ty + R) * P + RZ + V * tq];
             // every neighbour value is folded into the sums as soon as it is read (one FMA per
