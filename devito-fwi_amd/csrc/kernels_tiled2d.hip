@@ -105,22 +105,124 @@ __device__ inline void st4_half_stream_at(char *base, unsigned off, float4 v, fl
     __builtin_nontemporal_store(t, reinterpret_cast<vuint2_2d *>(base + (off >> 1)));
 }
 
+#ifndef MIFWI_2D_V2_BLOCKS
+#define MIFWI_2D_V2_BLOCKS 8   /* waves per SIMD: four 512-thread blocks per CU, 64 VGPRs */
+#endif
+// V consecutive points (V = 2 or 4) as one aligned 8- or 16-byte access
+template <int V>
+struct PV {
+    float v[V];
+};
+typedef float vfloat2_2d __attribute__((ext_vector_type(2)));
+template <int V>
+struct VT2;
+template <>
+struct VT2<2> {
+    typedef vfloat2_2d type;
+};
+template <>
+struct VT2<4> {
+    typedef vfloat4_2d type;
+};
+template <int V>
+__device__ inline PV<V> pv_fill(float x)
+{
+    PV<V> r;
+#pragma unroll
+    for (int i = 0; i < V; ++i) r.v[i] = x;
+    return r;
+}
+template <int V>
+__device__ inline PV<V> pv_ld(const char *base, unsigned off)
+{
+    const typename VT2<V>::type t = *reinterpret_cast<const typename VT2<V>::type *>(base + off);
+    PV<V> r;
+#pragma unroll
+    for (int i = 0; i < V; ++i) r.v[i] = t[i];
+    return r;
+}
+template <int V>
+__device__ inline PV<V> pv_ld_stream(const char *base, unsigned off)
+{
+#ifdef MIFWI_2D_NT_LOAD
+    const typename VT2<V>::type t = __builtin_nontemporal_load(reinterpret_cast<const typename VT2<V>::type *>(base + off));
+#else
+    const typename VT2<V>::type t = *reinterpret_cast<const typename VT2<V>::type *>(base + off);
+#endif
+    PV<V> r;
+#pragma unroll
+    for (int i = 0; i < V; ++i) r.v[i] = t[i];
+    return r;
+}
+template <int V>
+__device__ inline void pv_st(char *base, unsigned off, const float (&d)[V])
+{
+    typename VT2<V>::type t;
+#pragma unroll
+    for (int i = 0; i < V; ++i) t[i] = d[i];
+    *reinterpret_cast<typename VT2<V>::type *>(base + off) = t;
+}
+template <int V>
+__device__ inline void pv_st_stream(char *base, unsigned off, const float (&d)[V])
+{
+    typename VT2<V>::type t;
+#pragma unroll
+    for (int i = 0; i < V; ++i) t[i] = d[i];
+    __builtin_nontemporal_store(t, reinterpret_cast<typename VT2<V>::type *>(base + off));
+}
+// half-precision saved levels: `off` is the byte offset the same points have in a float field
+template <int V>
+__device__ inline PV<V> pv_ld_half_stream(const char *base, unsigned off, float inv_scale)
+{
+    PV<V> r;
+    if (V == 4) {
+        const vuint2_2d t = __builtin_nontemporal_load(reinterpret_cast<const vuint2_2d *>(base + (off >> 1)));
+        unpack_half2(t.x, r.v[0], r.v[1]);
+        unpack_half2(t.y, r.v[V - 2], r.v[V - 1]);
+    } else {
+        const unsigned t = __builtin_nontemporal_load(reinterpret_cast<const unsigned *>(base + (off >> 1)));
+        unpack_half2(t, r.v[0], r.v[1]);
+    }
+#pragma unroll
+    for (int i = 0; i < V; ++i) r.v[i] *= inv_scale;
+    return r;
+}
+template <int V>
+__device__ inline void pv_st_half_stream(char *base, unsigned off, const float (&d)[V], float scale)
+{
+    if (V == 4) {
+        vuint2_2d t;
+        t.x = pack_half2(d[0] * scale, d[1] * scale);
+        t.y = pack_half2(d[V - 2] * scale, d[V - 1] * scale);
+        __builtin_nontemporal_store(t, reinterpret_cast<vuint2_2d *>(base + (off >> 1)));
+    } else {
+        __builtin_nontemporal_store(pack_half2(d[0] * scale, d[1] * scale), reinterpret_cast<unsigned *>(base + (off >> 1)));
+    }
+}
+template <int V>
+__device__ inline void pv_lds_ld(const float *p, float (&d)[V])
+{
+    const typename VT2<V>::type t = *reinterpret_cast<const typename VT2<V>::type *>(p);
+#pragma unroll
+    for (int i = 0; i < V; ++i) d[i] = t[i];
+}
+
 // MODE 0: plain propagation, 1: gradient, 2: scattered field of Born modelling, 4: gradient of two steps
 // (a.pair): the step before ran as MODE 0 and its terms are added here, which halves the read-modify-write
-// traffic of the accumulators.
-template <int R, int TX, int TZ, int MODE>
+// traffic of the accumulators.  V: points per thread (TX*TZ/V threads per block).
+template <int R, int TX, int TZ, int MODE, int V>
 // Register budget of the gradient variant: 128 VGPRs, i.e. four blocks per CU (unconstrained it takes
 // 136 and three).  A batch of 8 shots is ~3.1 tiles per CU, so with three resident blocks the last
 // tiles of a launch wait for a free slot: 7.6 -> 6.6 us per step.  The plain variant fits anyway and
 // schedules better without the bound.
-__global__ __launch_bounds__(TX *TZ / 4, (MODE == 1 || MODE == 4) ? 4 : 1) void step2d_kernel(Step2DArgs a)
+__global__ __launch_bounds__(TX *TZ / V, V == 2 ? MIFWI_2D_V2_BLOCKS : ((MODE == 1 || MODE == 4) ? 4 : 1)) void step2d_kernel(Step2DArgs a)
 {
     constexpr bool GRAD = (MODE == 1 || MODE == 4), PAIR = (MODE == 4), BORN = (MODE == 2);
     constexpr int RZ = (R + 3) / 4 * 4;          // z halo in LDS, multiple of 4
     constexpr int ROWF4 = (TZ + 2 * RZ) / 4;     // float4 per staged row
     constexpr int P = tile2d_lds_pitch(TZ, R);   // LDS row pitch in floats
-    constexpr int TQ = TZ / 4;                   // threads per tile row
-    constexpr int NT = TX * TQ;                   // threads per block: one float4 of the tile each
+    constexpr int TQ = TZ / V;                   // threads per tile row
+    constexpr int NT = TX * TQ;                   // threads per block: V points of the tile each
     constexpr int NSTAGE = ((TX + 2 * R) * ROWF4 + NT - 1) / NT;  // staged float4 per thread
     static_assert(NT % 64 == 0 && NT <= 1024, "whole wavefronts");
     __shared__ __attribute__((aligned(16))) float lds[(TX + 2 * R) * P];
@@ -150,7 +252,7 @@ __global__ __launch_bounds__(TX *TZ / 4, (MODE == 1 || MODE == 4) ? 4 : 1) void 
     const int tile_x = tile / a.ntz, tile_z = tile - tile_x * a.ntz;
     const int x0 = tile_x * TX, z0 = tile_z * TZ;
     const int tx = tid / TQ, tq = tid - tx * TQ;
-    const int x = x0 + tx, z = z0 + 4 * tq;
+    const int x = x0 + tx, z = z0 + V * tq;
     const bool live = (x < a.n1) && (z < a.n2);
     const long p = a.off0 + (long)x * a.s1 + z;
     const long ps = (long)shot * a.shot_stride + p;
@@ -172,44 +274,45 @@ __global__ __launch_bounds__(TX *TZ / 4, (MODE == 1 || MODE == 4) ? 4 : 1) void 
         if (c < (TX + 2 * R) * ROWF4 && gx < a.n1 + R)
             stage[i] = ld4_at(curb, (unsigned)((int)a.off0 + gx * (int)a.s1 + (z0 - RZ + 4 * q)) * 4u);
     }
-    float4 m4 = make_float4(1.f, 1.f, 1.f, 1.f), e4 = make_float4(0.f, 0.f, 0.f, 0.f), o4 = e4;
-    float4 u04 = e4, up4 = e4, gv = e4, iv = e4, po4 = e4;
-    float4 bn4 = e4, bc4 = e4, bo4 = e4, bd4 = e4;
+    PV<V> m4 = pv_fill<V>(1.f), e4 = pv_fill<V>(0.f), o4 = e4;
+    PV<V> u04 = e4, up4 = e4, gv = e4, iv = e4, po4 = e4;
+    PV<V> bn4 = e4, bc4 = e4, bo4 = e4, bd4 = e4;
     const long gs = (long)shot * a.g_shot_stride + p;
     if (live) {
-        m4 = ld4_at(reinterpret_cast<const char *>(a.m), pb);
-        e4 = ld4_at(reinterpret_cast<const char *>(a.eta), pb);
-        o4 = ld4_at(oldb, pb);
+        m4 = pv_ld<V>(reinterpret_cast<const char *>(a.m), pb);
+        e4 = pv_ld<V>(reinterpret_cast<const char *>(a.eta), pb);
+        o4 = pv_ld<V>(oldb, pb);
         if (GRAD) {
             if (a.save_scale) {   // half-precision saved levels (block-uniform branch)
                 const float inv = 1.0f / a.save_scale[shot];
                 const long hs = (long)shot * a.u_shot_stride * 2;
-                u04 = ld4_half_stream_at(reinterpret_cast<const char *>(a.uc) + hs, pb, inv);
+                u04 = pv_ld_half_stream<V>(reinterpret_cast<const char *>(a.uc) + hs, pb, inv);
                 if (PAIR || (a.first && a.illum))
-                    up4 = ld4_half_stream_at(reinterpret_cast<const char *>(a.up) + hs, pb, inv);
+                    up4 = pv_ld_half_stream<V>(reinterpret_cast<const char *>(a.up) + hs, pb, inv);
             } else {
-                u04 = ld4_stream_at(reinterpret_cast<const char *>(a.uc + (long)shot * a.u_shot_stride), pb);
+                u04 = pv_ld_stream<V>(reinterpret_cast<const char *>(a.uc + (long)shot * a.u_shot_stride), pb);
                 if (PAIR)
-                    up4 = ld4_stream_at(reinterpret_cast<const char *>(a.up + (long)shot * a.u_shot_stride), pb);
+                    up4 = pv_ld_stream<V>(reinterpret_cast<const char *>(a.up + (long)shot * a.u_shot_stride), pb);
                 else if (a.first && a.illum)
-                    up4 = ld4_at(reinterpret_cast<const char *>(a.up + (long)shot * a.u_shot_stride), pb);
+                    up4 = pv_ld<V>(reinterpret_cast<const char *>(a.up + (long)shot * a.u_shot_stride), pb);
             }
-            if (PAIR) po4 = ld4_at(outb, pb);   // backward level time + 2, about to be overwritten
-            gv = ld4_at(reinterpret_cast<const char *>(a.grad + (long)shot * a.g_shot_stride), pb);
-            if (a.illum) iv = ld4_at(reinterpret_cast<const char *>(a.illum + (long)shot * a.g_shot_stride), pb);
+            if (PAIR) po4 = pv_ld<V>(outb, pb);   // backward level time + 2, about to be overwritten
+            gv = pv_ld<V>(reinterpret_cast<const char *>(a.grad + (long)shot * a.g_shot_stride), pb);
+            if (a.illum) iv = pv_ld<V>(reinterpret_cast<const char *>(a.illum + (long)shot * a.g_shot_stride), pb);
         }
         if (BORN) {
-            bn4 = ld4_at(reinterpret_cast<const char *>(a.b_un + (long)shot * a.b_shot_stride), pb);
-            bc4 = ld4_at(reinterpret_cast<const char *>(a.b_uc + (long)shot * a.b_shot_stride), pb);
-            bo4 = ld4_at(reinterpret_cast<const char *>(a.b_uo + (long)shot * a.b_shot_stride), pb);
-            bd4 = ld4_at(reinterpret_cast<const char *>(a.b_dm), pb);
+            bn4 = pv_ld<V>(reinterpret_cast<const char *>(a.b_un + (long)shot * a.b_shot_stride), pb);
+            bc4 = pv_ld<V>(reinterpret_cast<const char *>(a.b_uc + (long)shot * a.b_shot_stride), pb);
+            bo4 = pv_ld<V>(reinterpret_cast<const char *>(a.b_uo + (long)shot * a.b_shot_stride), pb);
+            bd4 = pv_ld<V>(reinterpret_cast<const char *>(a.b_dm), pb);
         }
     }
 
     // ---- injected terms of the cells this tile owns (rare: block-uniform branch): the terms were
     // formed before the time loop, so both loads are independent of everything else in flight
     if (ninj > 0) {
-        *reinterpret_cast<float4 *>(&acc[4 * tid]) = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int i = 0; i < V; ++i) acc[V * tid + i] = 0.f;
         __syncthreads();
         const long tslot = (long)inj_tab * (a.ntx * a.ntz) + tile;
         const float *w = a.winj + ((long)shot * a.nt + a.time) * a.winj_stride + a.slot_base[tslot];
@@ -226,60 +329,58 @@ __global__ __launch_bounds__(TX *TZ / 4, (MODE == 1 || MODE == 4) ? 4 : 1) void 
     __syncthreads();
 
     if (live) {
-        const float *ctr = &lds[(tx + R) * P + RZ + 4 * tq];
-        // z line: floats -RZ .. 4+RZ-1 around the 4 centre points
-        float f[4 + 2 * RZ];
+        const float *ctr = &lds[(tx + R) * P + RZ + V * tq];
+        // z line: floats -RZ .. V+RZ-1 around the V centre points
+        float f[V + 2 * RZ];
 #pragma unroll
-        for (int q = 0; q < (4 + 2 * RZ) / 4; ++q) {
-            const float4 v = *reinterpret_cast<const float4 *>(ctr - RZ + 4 * q);
-            f[4 * q + 0] = v.x, f[4 * q + 1] = v.y, f[4 * q + 2] = v.z, f[4 * q + 3] = v.w;
+        for (int q = 0; q < (V + 2 * RZ) / V; ++q) {
+            float t[V];
+            pv_lds_ld<V>(ctr - RZ + V * q, t);
+#pragma unroll
+            for (int i = 0; i < V; ++i) f[V * q + i] = t[i];
         }
-        float lap[4], uc[4];
+        float lap[V], uc[V];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < V; ++i) {
             uc[i] = f[RZ + i];
             lap[i] = a.c0 * uc[i];
         }
 #pragma unroll
         for (int k = 1; k <= R; ++k) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) lap[i] += a.cz[k] * (f[RZ + i - k] + f[RZ + i + k]);
+            for (int i = 0; i < V; ++i) lap[i] += a.cz[k] * (f[RZ + i - k] + f[RZ + i + k]);
         }
 #pragma unroll
         for (int k = 1; k <= R; ++k) {
-            const float4 lo = *reinterpret_cast<const float4 *>(ctr - k * P);
-            const float4 hi = *reinterpret_cast<const float4 *>(ctr + k * P);
-            lap[0] += a.cx[k] * (lo.x + hi.x);
-            lap[1] += a.cx[k] * (lo.y + hi.y);
-            lap[2] += a.cx[k] * (lo.z + hi.z);
-            lap[3] += a.cx[k] * (lo.w + hi.w);
-        }
-        const float mm[4] = {m4.x, m4.y, m4.z, m4.w}, ee[4] = {e4.x, e4.y, e4.z, e4.w},
-                    oo[4] = {o4.x, o4.y, o4.z, o4.w};
-        float res[4];
+            float lo[V], hi[V];
+            pv_lds_ld<V>(ctr - k * P, lo);
+            pv_lds_ld<V>(ctr + k * P, hi);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < V; ++i) lap[i] += a.cx[k] * (lo[i] + hi[i]);
+        }
+        const float(&mm)[V] = m4.v, (&ee)[V] = e4.v, (&oo)[V] = o4.v;
+        float res[V];
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
             const float ed = ee[i] * a.dt;
             res[i] = fast_div(a.dt2 * lap[i] + 2.0f * mm[i] * uc[i] - mm[i] * oo[i] + ed * uc[i], mm[i] + ed);
         }
         if (BORN) {
-            const float bn[4] = {bn4.x, bn4.y, bn4.z, bn4.w}, bc[4] = {bc4.x, bc4.y, bc4.z, bc4.w},
-                        bo[4] = {bo4.x, bo4.y, bo4.z, bo4.w}, bd[4] = {bd4.x, bd4.y, bd4.z, bd4.w};
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const float utt = (bn[i] - 2.0f * bc[i] + bo[i]) * a.inv_dt2;
-                res[i] += fast_div(a.dt2 * (-bd[i] * utt), mm[i] + ee[i] * a.dt);
+            for (int i = 0; i < V; ++i) {
+                const float utt = (bn4.v[i] - 2.0f * bc4.v[i] + bo4.v[i]) * a.inv_dt2;
+                res[i] += fast_div(a.dt2 * (-bd4.v[i] * utt), mm[i] + ee[i] * a.dt);
             }
         }
         if (ninj > 0) {
-            const float4 add = *reinterpret_cast<const float4 *>(&acc[4 * tid]);
-            res[0] += add.x, res[1] += add.y, res[2] += add.z, res[3] += add.w;
+#pragma unroll
+            for (int i = 0; i < V; ++i) res[i] += acc[V * tid + i];
         }
-        const bool full = (z + 3 < a.n2);
+        const bool full = (z + V - 1 < a.n2);
         if (full) {
-            st4_at(outb, pb, make_float4(res[0], res[1], res[2], res[3]));
+            pv_st<V>(outb, pb, res);
         } else {
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < V; ++i)
                 if (z + i < a.n2) a.out[ps + i] = res[i];
         }
         if (a.copy) {
@@ -289,24 +390,23 @@ __global__ __launch_bounds__(TX *TZ / 4, (MODE == 1 || MODE == 4) ? 4 : 1) void 
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
                 if (!dsts[c]) continue;   // block-uniform
-                const float *val = c ? uc : res;
+                const float(&val)[V] = c ? uc : res;
                 if (a.save_scale) {
                     const float sc = a.save_scale[shot];
                     char *cb = reinterpret_cast<char *>(dsts[c]) + (long)shot * a.copy_shot_stride * 2;
                     if (full) {
-                        st4_half_stream_at(cb, pb, make_float4(val[0], val[1], val[2], val[3]), sc);
+                        pv_st_half_stream<V>(cb, pb, val, sc);
                     } else {
                         __half *ch = reinterpret_cast<__half *>(cb) + p;
-                        for (int i = 0; i < 4; ++i)
+                        for (int i = 0; i < V; ++i)
                             if (z + i < a.n2) ch[i] = __float2half_rn(fminf(fmaxf(val[i] * sc, -65504.0f), 65504.0f));
                     }
                 } else {
                     float *cp = dsts[c] + (long)shot * a.copy_shot_stride + p;
                     if (full) {
-                        st4_stream_at(reinterpret_cast<char *>(dsts[c] + (long)shot * a.copy_shot_stride), pb,
-                                      make_float4(val[0], val[1], val[2], val[3]));
+                        pv_st_stream<V>(reinterpret_cast<char *>(dsts[c] + (long)shot * a.copy_shot_stride), pb, val);
                     } else {
-                        for (int i = 0; i < 4; ++i)
+                        for (int i = 0; i < V; ++i)
                             if (z + i < a.n2) cp[i] = val[i];
                     }
                 }
@@ -316,25 +416,26 @@ __global__ __launch_bounds__(TX *TZ / 4, (MODE == 1 || MODE == 4) ? 4 : 1) void 
             // free surface: row -zi of the z halo mirrors row zi with the opposite sign, so that the
             // next step's stencil reads the antisymmetric extension (operators.py:8-35)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < V; ++i) {
                 const int zi = z + i;
                 if (zi >= 1 && zi <= R && zi < a.n2) a.out[ps - z - zi] = -res[i];
             }
         }
         if (GRAD) {
-            const float u0[4] = {u04.x, u04.y, u04.z, u04.w}, up[4] = {up4.x, up4.y, up4.z, up4.w};
-            float g[4] = {gv.x, gv.y, gv.z, gv.w}, il[4] = {iv.x, iv.y, iv.z, iv.w};
+            const float(&u0)[V] = u04.v, (&up)[V] = up4.v;
+            float g[V], il[V];
+#pragma unroll
+            for (int i = 0; i < V; ++i) g[i] = gv.v[i], il[i] = iv.v[i];
             if (PAIR) {
                 // terms of the step before (time + 1), added first: the sums keep their order in time
-                const float po[4] = {po4.x, po4.y, po4.z, po4.w};
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    g[i] = grad_accumulate(g[i], po[i], oo[i], uc[i], up[i], a.inv_dt2);
+                for (int i = 0; i < V; ++i) {
+                    g[i] = grad_accumulate(g[i], po4.v[i], oo[i], uc[i], up[i], a.inv_dt2);
                     il[i] = illum_accumulate(il[i], up[i]);
                 }
             }
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < V; ++i) {
                 // zero-lag correlation, summed by parts over time: the second time difference is taken
                 // of the backward field (all three levels are in registers here) instead of the saved
                 // forward field, so one saved level is read per step instead of three
@@ -345,12 +446,10 @@ __global__ __launch_bounds__(TX *TZ / 4, (MODE == 1 || MODE == 4) ? 4 : 1) void 
                     il[i] = illum_accumulate(il[i], u0[i]);
             }
             if (full) {
-                st4_at(reinterpret_cast<char *>(a.grad + (long)shot * a.g_shot_stride), pb, make_float4(g[0], g[1], g[2], g[3]));
-                if (a.illum)
-                    st4_at(reinterpret_cast<char *>(a.illum + (long)shot * a.g_shot_stride), pb,
-                           make_float4(il[0], il[1], il[2], il[3]));
+                pv_st<V>(reinterpret_cast<char *>(a.grad + (long)shot * a.g_shot_stride), pb, g);
+                if (a.illum) pv_st<V>(reinterpret_cast<char *>(a.illum + (long)shot * a.g_shot_stride), pb, il);
             } else {
-                for (int i = 0; i < 4; ++i)
+                for (int i = 0; i < V; ++i)
                     if (z + i < a.n2) {
                         a.grad[gs + i] = g[i];
                         if (a.illum) a.illum[gs + i] = il[i];
@@ -360,19 +459,31 @@ __global__ __launch_bounds__(TX *TZ / 4, (MODE == 1 || MODE == 4) ? 4 : 1) void 
     }
 }
 
-template <int R, int TX, int TZ>
-static int launch_rt(const Plan &p, const Step2DArgs &a, int nblocks, hipStream_t stream)
+template <int R, int TX, int TZ, int V>
+static int launch_rtv(const Plan &p, const Step2DArgs &a, hipStream_t stream)
 {
+    constexpr int NT = TX * TZ / V;
+    const int nblocks = a.ntx * a.ntz * a.nshots + (a.pt_idx ? ((a.itp_npoint + NT - 1) / NT) * a.nshots : 0);
     if (a.um && a.pair)
-        hipLaunchKernelGGL((step2d_kernel<R, TX, TZ, 4>), dim3(nblocks), dim3(TX * TZ / 4), 0, stream, a);
+        hipLaunchKernelGGL((step2d_kernel<R, TX, TZ, 4, V>), dim3(nblocks), dim3(NT), 0, stream, a);
     else if (a.um)
-        hipLaunchKernelGGL((step2d_kernel<R, TX, TZ, 1>), dim3(nblocks), dim3(TX * TZ / 4), 0, stream, a);
+        hipLaunchKernelGGL((step2d_kernel<R, TX, TZ, 1, V>), dim3(nblocks), dim3(NT), 0, stream, a);
     else if (a.b_un)
-        hipLaunchKernelGGL((step2d_kernel<R, TX, TZ, 2>), dim3(nblocks), dim3(TX * TZ / 4), 0, stream, a);
+        hipLaunchKernelGGL((step2d_kernel<R, TX, TZ, 2, V>), dim3(nblocks), dim3(NT), 0, stream, a);
     else
-        hipLaunchKernelGGL((step2d_kernel<R, TX, TZ, 0>), dim3(nblocks), dim3(TX * TZ / 4), 0, stream, a);
+        hipLaunchKernelGGL((step2d_kernel<R, TX, TZ, 0, V>), dim3(nblocks), dim3(NT), 0, stream, a);
     MIFWI_HIP(hipGetLastError());
     return MIFWI_OK;
+}
+
+template <int R, int TX, int TZ>
+static int launch_rt(const Plan &p, const Step2DArgs &a, int, hipStream_t stream)
+{
+    // two points per thread (twice the waves per tile) is an experiment of the 32 x 32 tile only
+    if constexpr (TX == 32 && TZ == 32) {
+        if (p.vec2d == 2) return launch_rtv<R, TX, TZ, 2>(p, a, stream);
+    }
+    return launch_rtv<R, TX, TZ, 4>(p, a, stream);
 }
 
 template <int R>

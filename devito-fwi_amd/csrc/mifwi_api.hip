@@ -455,6 +455,7 @@ static int create(const mifwi_config *cfg, mifwi_plan **out)
     }
     if (const char *env = getenv("MIFWI_PAIR_GRAD")) p->pair_grad = atoi(env);  // tuning experiments
     if (const char *env = getenv("MIFWI_PAIR_SAVE")) p->pair_save = atoi(env);  // tuning experiments
+    if (const char *env = getenv("MIFWI_2D_VEC")) p->vec2d = atoi(env);  // tuning experiments
     if (cfg->ndim == 2 && cfg->dtype == MIFWI_F32 && !(cfg->flags & (MIFWI_FLAG_GENERIC | MIFWI_FLAG_OT4))) {
         // tiled fast path: pick the tile shape that wastes fewer threads on this grid
         const int n1 = p->L.n[1], n2 = p->L.n[2];

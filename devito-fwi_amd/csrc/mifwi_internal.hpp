@@ -156,6 +156,7 @@ struct Plan {
     int nchunk_env = 0;
     unsigned char *eta_zero = nullptr;  // 2.5-D kernel: [tile][n0] flags of sponge-free patches
     int vec3d = 0;  // points per thread of the 2.5-D kernel: 0 = by stencil radius, else 2 or 4
+    int vec2d = 4;      // points per thread of the tiled 2-D kernel (2: experiment, 32 x 32 tiles only)
     int pair_save = 1;  // saving forward loops of the tiled 2-D kernel write two saved levels every second step
     int pair_grad = 1;  // gradient loops update the accumulators every second step (tiled kernels)
 
