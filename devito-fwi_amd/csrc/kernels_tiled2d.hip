@@ -37,72 +37,13 @@ __device__ inline float fast_div(float a, float b)
 }
 
 typedef float vfloat4_2d __attribute__((ext_vector_type(4)));
-__device__ inline void st4_out(float *p, float4 v)
-{
-#ifdef MIFWI_2D_NT_STORE
-    vfloat4_2d t = {v.x, v.y, v.z, v.w};
-    __builtin_nontemporal_store(t, reinterpret_cast<vfloat4_2d *>(p));
-#else
-    *reinterpret_cast<float4 *>(p) = v;
-#endif
-}
+typedef unsigned vuint2_2d __attribute__((ext_vector_type(2)));
 // 16-byte accesses addressed as a block-uniform (SGPR) base pointer plus a 32-bit per-lane byte offset:
 // the cheapest global addressing mode, no 64-bit vector address arithmetic.  One field level stays
 // below 4 GB (checked when the plan is created).
 __device__ inline float4 ld4_at(const char *base, unsigned off)
 {
     return *reinterpret_cast<const float4 *>(base + off);
-}
-__device__ inline float4 ld4_stream_at(const char *base, unsigned off)
-{
-#ifdef MIFWI_2D_NT_LOAD
-    const vfloat4_2d v = __builtin_nontemporal_load(reinterpret_cast<const vfloat4_2d *>(base + off));
-    return make_float4(v.x, v.y, v.z, v.w);
-#else
-    return *reinterpret_cast<const float4 *>(base + off);
-#endif
-}
-__device__ inline void st4_at(char *base, unsigned off, float4 v)
-{
-    *reinterpret_cast<float4 *>(base + off) = v;
-}
-__device__ inline void st4_stream_at(char *base, unsigned off, float4 v)
-{
-    vfloat4_2d t = {v.x, v.y, v.z, v.w};
-    __builtin_nontemporal_store(t, reinterpret_cast<vfloat4_2d *>(base + off));
-}
-__device__ inline void st4_stream(float *p, float4 v)
-{
-    vfloat4_2d t = {v.x, v.y, v.z, v.w};
-    __builtin_nontemporal_store(t, reinterpret_cast<vfloat4_2d *>(p));
-}
-__device__ inline float4 ld4_saved(const float *p)
-{
-#ifdef MIFWI_2D_NT_LOAD
-    const vfloat4_2d v = __builtin_nontemporal_load(reinterpret_cast<const vfloat4_2d *>(p));
-    return make_float4(v.x, v.y, v.z, v.w);
-#else
-    return *reinterpret_cast<const float4 *>(p);
-#endif
-}
-
-// Four consecutive points of a half-precision saved level: `off` is the byte offset the same points have
-// in a float field, so the halves sit at off / 2 (8-byte aligned).
-typedef unsigned vuint2_2d __attribute__((ext_vector_type(2)));
-__device__ inline float4 ld4_half_stream_at(const char *base, unsigned off, float inv_scale)
-{
-    const vuint2_2d v = __builtin_nontemporal_load(reinterpret_cast<const vuint2_2d *>(base + (off >> 1)));
-    float4 r;
-    unpack_half2(v.x, r.x, r.y);
-    unpack_half2(v.y, r.z, r.w);
-    return make_float4(r.x * inv_scale, r.y * inv_scale, r.z * inv_scale, r.w * inv_scale);
-}
-__device__ inline void st4_half_stream_at(char *base, unsigned off, float4 v, float scale)
-{
-    vuint2_2d t;
-    t.x = pack_half2(v.x * scale, v.y * scale);
-    t.y = pack_half2(v.z * scale, v.w * scale);
-    __builtin_nontemporal_store(t, reinterpret_cast<vuint2_2d *>(base + (off >> 1)));
 }
 
 #ifndef MIFWI_2D_V2_BLOCKS
