@@ -1165,10 +1165,10 @@ static int run_backward(Plan &p, int nshots, bool with_grad, bool with_illum)
     // time runs as a plain propagation (role 1) and the following one, at the odd time below it, adds both
     // steps' terms (role 2).  Roles depend on the time index alone, so a checkpointed loop (segments start
     // at odd times) runs the same kernel at every step as the fully saved one.
-    // Measured on 592^3 at order 8: with half-precision saved levels the backward loop takes 615 instead
-    // of 670 ms, with float levels (checkpointed) 637 instead of 596 ms, so the 2.5-D kernel pairs only in
-    // the first case (pair_grad == 2 forces it).
-    const bool pair_grad = with_grad && p.pair_grad && (p.kind == 1 || (p.kind == 2 && (p.save_f16 || p.pair_grad == 2)));
+    // Measured on 592^3 (2.5-D kernel): backward loop at order 8 with half-precision levels 670 -> 608 ms,
+    // checkpointed with float levels 1084 -> 1033 ms (recomputation included); fully saved float levels,
+    // nt = 200: order 16 291 -> 272 ms, order 4 256 -> 242 ms.
+    const bool pair_grad = with_grad && p.pair_grad && p.kind != 0;
     auto pair_role = [&](int time) {
         if (!pair_grad) return 0;
         if (time % 2 == 0) return (time != nt - 2 && time >= 2) ? 1 : 0;
