@@ -527,13 +527,22 @@ template int launch_l2_misfit<double>(const Plan &, const double *, const double
 // beyond it saturate -- with 11 significant bits down to 8e-8 of the peak (the error is the mantissa
 // rounding either way: scales of 16 and 256 gave the same gradients to three digits).  A silent shot gets scale 1.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void save_scale_kernel(const float *winj, long per_shot, float *scale)
+// Only the slots g < uc_count[table] of a (shot, time) row hold terms (inject_prepare_kernel writes no others);
+// the rest of the row is whatever the buffer held before and is skipped.
+__global__ __launch_bounds__(256) void save_scale_kernel(const float *winj, int nt, int kmax, const int32_t *uc_count,
+                                                         int per_shot_tables, float *scale)
 {
     __shared__ float red[256];
     const int shot = blockIdx.x;
     float m = 0.f;
-    if (winj)
-        for (long i = threadIdx.x; i < per_shot; i += 256) m = fmaxf(m, fabsf(winj[(long)shot * per_shot + i]));
+    if (winj) {
+        const int count = uc_count[per_shot_tables ? shot : 0];
+        const float *w = winj + (long)shot * nt * kmax;
+        for (long i = threadIdx.x; i < (long)nt * count; i += 256) {
+            const long time = i / count;
+            m = fmaxf(m, fabsf(w[time * kmax + (i - time * count)]));
+        }
+    }
     red[threadIdx.x] = m;
     __syncthreads();
     for (int s = 128; s > 0; s >>= 1) {
@@ -543,9 +552,10 @@ __global__ __launch_bounds__(256) void save_scale_kernel(const float *winj, long
     if (threadIdx.x == 0) scale[shot] = (red[0] > 0.f && isfinite(red[0])) ? 64.0f / red[0] : 1.0f;
 }
 
-int launch_save_scale(const Plan &p, const float *winj, long per_shot, int nshots, float *scale)
+int launch_save_scale(const Plan &p, const float *winj, const SparseSet &S, int nshots, float *scale)
 {
-    hipLaunchKernelGGL(save_scale_kernel, dim3(nshots), dim3(256), 0, p.stream, winj, per_shot, scale);
+    hipLaunchKernelGGL(save_scale_kernel, dim3(nshots), dim3(256), 0, p.stream, winj, p.cfg.nt, S.kmax, S.uc_count,
+                       S.per_shot, scale);
     MIFWI_HIP(hipGetLastError());
     return MIFWI_OK;
 }

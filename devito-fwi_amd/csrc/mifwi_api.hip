@@ -156,6 +156,7 @@ static void destroy(Plan *p)
     free_sparse(p->src);
     free_sparse(p->rec);
     dev_free(p->d_wavelet);
+    dev_free(p->d_wavelet_ck);
     dev_free(p->d_rec);
     dev_free(p->d_res);
     dev_free(p->d_srca);
@@ -176,8 +177,9 @@ static void destroy(Plan *p)
     dev_free(p->d_partial);
     dev_free(p->d_fval);
     dev_free(p->eta_zero);
-    if (p->ev0) (void)hipEventDestroy(p->ev0);
-    if (p->ev1) (void)hipEventDestroy(p->ev1);
+    for (auto &pair : p->ev)
+        for (hipEvent_t e : pair)
+            if (e) (void)hipEventDestroy(e);
     if (p->own_stream && p->stream) (void)hipStreamDestroy(p->stream);
     delete p;
 }
@@ -490,8 +492,9 @@ static int create(const mifwi_config *cfg, mifwi_plan **out)
     if (hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking) != hipSuccess)
         return bail(fail(MIFWI_EHIP, "hipStreamCreate failed"));
     p->own_stream = true;
-    if (hipEventCreate(&p->ev0) != hipSuccess || hipEventCreate(&p->ev1) != hipSuccess)
-        return bail(fail(MIFWI_EHIP, "hipEventCreate failed"));
+    for (auto &pair : p->ev)
+        for (hipEvent_t &e : pair)
+            if (hipEventCreate(&e) != hipSuccess) return bail(fail(MIFWI_EHIP, "hipEventCreate failed"));
     const size_t es = p->esize;
     const size_t field = (size_t)p->L.field;
     const size_t S = (size_t)cfg->max_shots;
@@ -534,6 +537,11 @@ static int set_model(Plan &p, const void *vp, const void *damp)
         damp_dev = ddamp;
     }
     if ((rc = launch_prep_model<T>(p, vp_dev, damp_dev, (T *)p.m, (T *)p.eta))) return rc;
+    if (p.ck_K > 0 && p.saved_valid) {
+        // checkpoints are re-propagated with the model at hand: those of the previous model are of no use now
+        p.saved_valid = false;
+        p.ck_model_changed = true;
+    }
     if (p.kind == 2) {
         if (!p.eta_zero && (rc = dev_alloc(p, (void **)&p.eta_zero, (size_t)p.ntx * p.ntz * p.L.n[0], true))) return rc;
         if ((rc = launch_eta_zero(p, p.eta_zero))) return rc;
@@ -590,6 +598,31 @@ static void fill_stats(Plan &p, double ms, double steps, int nshots, double byte
     p.stats.launches = launches;
     p.stats.kernel_kind = p.kind;
     p.stats.device_bytes = p.device_bytes;
+    // MIFWI_FLAG_ASYNC: the loop has only been enqueued and ms is unknown; resolve_stats() fills the times in
+    p.timing_pending[backward ? 1 : 0] = (p.cfg.flags & MIFWI_FLAG_ASYNC) != 0;
+    p.timing_last = backward ? 1 : 0;
+    p.timing_sum = false;
+}
+
+// Times of loops that were enqueued without waiting (MIFWI_FLAG_ASYNC): read the events once they have
+// completed.  Blocks until they have; called by mifwi_get_stats and mifwi_synchronize.
+static int resolve_stats(Plan &p)
+{
+    if (!p.timing_pending[0] && !p.timing_pending[1]) return MIFWI_OK;
+    double sum = 0.0;
+    for (int b = 0; b < 2; ++b) {
+        if (!p.timing_pending[b]) continue;
+        float ms = 0;
+        MIFWI_HIP(hipEventSynchronize(p.ev[b][1]));
+        MIFWI_HIP(hipEventElapsedTime(&ms, p.ev[b][0], p.ev[b][1]));
+        (b ? p.stats.bwd_ms : p.stats.fwd_ms) = ms;
+        sum += ms;
+        if (!p.timing_sum && b == p.timing_last) p.stats.kernel_ms = ms;
+        p.timing_pending[b] = false;
+    }
+    if (p.timing_sum) p.stats.kernel_ms = sum;
+    p.stats.gpointss = p.stats.kernel_ms > 0 ? p.stats.points / (p.stats.kernel_ms * 1e-3) / 1e9 : 0.0;
+    return MIFWI_OK;
 }
 
 template <typename T>
@@ -847,7 +880,7 @@ static int forward_step(Plan &p, const LoopCtx<T> &c, const T *cur, const T *old
     if (inject) {
         q.inj = &p.src;
         q.field_inj = out;
-        q.vals_inj = (const T *)p.d_wavelet;
+        q.vals_inj = (const T *)(p.wavelet_override ? p.wavelet_override : p.d_wavelet);
     }
     if (interp) {
         q.itp = &p.rec;
@@ -964,12 +997,15 @@ static int backward_step(Plan &p, const LoopCtx<T> &c, const T *cur, const T *ol
 // different hardware queues did not overlap on MI355X, 8 shots in 2/4/8 groups ran 1.2-3x slower
 // than one chain.)
 template <typename F>
-static int timed_loop(Plan &p, const std::tuple<int, int, int, int, int> *key, F &&enqueue, int &launches, float &ms)
+static int timed_loop(Plan &p, const std::tuple<int, int, int, int, int> *key, F &&enqueue, int &launches, float &ms,
+                      bool backward = false)
 {
     int rc = MIFWI_OK;
     launches = 0;
-    MIFWI_HIP(hipEventRecord(p.ev0, p.stream));
-    if (!key || (p.cfg.flags & MIFWI_FLAG_NO_GRAPH)) {
+    hipEvent_t e0 = p.ev[backward ? 1 : 0][0], e1 = p.ev[backward ? 1 : 0][1];
+    MIFWI_HIP(hipEventRecord(e0, p.stream));
+    // the legacy default stream (a null handle) cannot be captured: launch directly on it
+    if (!key || (p.cfg.flags & MIFWI_FLAG_NO_GRAPH) || p.stream == nullptr) {
         if ((rc = enqueue(launches))) return rc;
     } else {
         auto it = p.graphs.find(*key);
@@ -993,9 +1029,11 @@ static int timed_loop(Plan &p, const std::tuple<int, int, int, int, int> *key, F
         launches = it->second.second;
         MIFWI_HIP(hipGraphLaunch(it->second.first, p.stream));
     }
-    MIFWI_HIP(hipEventRecord(p.ev1, p.stream));
-    MIFWI_HIP(hipEventSynchronize(p.ev1));
-    MIFWI_HIP(hipEventElapsedTime(&ms, p.ev0, p.ev1));
+    MIFWI_HIP(hipEventRecord(e1, p.stream));
+    ms = 0;
+    if (p.cfg.flags & MIFWI_FLAG_ASYNC) return MIFWI_OK;   // the caller's fill_stats marks the time as pending
+    MIFWI_HIP(hipEventSynchronize(e1));
+    MIFWI_HIP(hipEventElapsedTime(&ms, e0, e1));
     return MIFWI_OK;
 }
 
@@ -1044,6 +1082,9 @@ static int prepare_save(Plan &p)
         return fail(MIFWI_ENOMEM, "not enough device memory even for the checkpointed wavefield (" +
                                       std::to_string(need >> 20) + " MiB needed)");
     if ((rc = dev_alloc(p, &p.ckpt, level * 2 * p.ck_nseg, true))) return rc;
+    // the recomputation must see the wavelet of the run that took the checkpoints, whatever is modelled between
+    if ((rc = dev_alloc(p, &p.d_wavelet_ck, (size_t)p.cfg.max_shots * nt * std::max(1, p.cfg.nsrc) * sizeof(T), true)))
+        return rc;
     return dev_alloc(p, &p.seg, level * (p.ck_K + 2), true);
 }
 
@@ -1083,7 +1124,7 @@ static int run_forward(Plan &p, int nshots, int save)
     if ((rc = prepare_injection<T>(p, p.src, p.d_wavelet, nshots))) return rc;
     if (copy_save && p.save_f16) {
         const bool have = p.src.npoint > 0 && p.src.max_count > 0;
-        if ((rc = launch_save_scale(p, have ? (const float *)p.d_winj[0] : nullptr, (long)nt * p.src.kmax, nshots,
+        if ((rc = launch_save_scale(p, have ? (const float *)p.d_winj[0] : nullptr, p.src, nshots,
                                     (float *)p.d_save_scale)))
             return rc;
     }
@@ -1092,6 +1133,11 @@ static int run_forward(Plan &p, int nshots, int save)
     const bool in_saved = full_save && !copy_save;
     auto lvl = [&](int t) { return in_saved ? base + (long)t * sv_lstride : base + (long)(t % 3) * L.field; };
     const bool ckpt = save && !full_save;
+    if (ckpt) {
+        MIFWI_HIP(hipMemcpyAsync(p.d_wavelet_ck, p.d_wavelet, (size_t)nshots * nt * std::max(1, p.cfg.nsrc) * sizeof(T),
+                                 hipMemcpyDeviceToDevice, p.stream));
+        p.ck_model_changed = false;
+    }
     auto enqueue = [&](int &launches) -> int {
         for (int time = 1; time <= nt - 2; ++time) {
             if (ckpt && (time - 1) % p.ck_K == 0) {
@@ -1143,6 +1189,9 @@ static int run_backward(Plan &p, int nshots, bool with_grad, bool with_illum)
     MIFWI_HIP(hipMemsetAsync(base, 0, (size_t)nshots * shot_stride * sizeof(T), p.stream));
     p.rot_v_valid = false;
     if (with_grad) {
+        if (!p.saved_valid && p.ck_model_changed)
+            return fail(MIFWI_ESTATE, "mifwi_set_model was called after the checkpoints of the forward wavefield were "
+                                      "taken: run forward(save=1) again with the new model");
         if (!p.saved_valid || p.saved_shots < nshots)
             return fail(MIFWI_ESTATE, "gradient needs the wavefield of a preceding forward(save=1) for these shots");
         if (!p.d_grad && (rc = dev_alloc(p, &p.d_grad, (size_t)p.cfg.max_shots * L.field * sizeof(T), true))) return rc;
@@ -1156,7 +1205,13 @@ static int run_backward(Plan &p, int nshots, bool with_grad, bool with_illum)
         MIFWI_HIP(hipMemsetAsync(p.d_srca, 0, (size_t)nshots * nt * p.cfg.nsrc * sizeof(T), p.stream));
     }
     if ((rc = prepare_injection<T>(p, p.rec, p.d_res, nshots))) return rc;
-    if (with_grad && p.ck_K > 0 && (rc = prepare_injection<T>(p, p.src, p.d_wavelet, nshots))) return rc;  // recomputation
+    if (with_grad && p.ck_K > 0 && (rc = prepare_injection<T>(p, p.src, p.d_wavelet_ck, nshots))) return rc;  // recomputation
+    // untiled kernels read the wavelet itself while recomputing: point them at the kept copy for this loop
+    struct Override {
+        Plan &p;
+        ~Override() { p.wavelet_override = nullptr; }
+    } override_guard{p};
+    if (with_grad && p.ck_K > 0) p.wavelet_override = p.d_wavelet_ck;
     const LoopCtx<T> ctx = make_ctx<T>(p, nshots, with_grad);
     const LoopCtx<T> fctx = make_ctx<T>(p, nshots, false);
     auto lvl = [&](int t) { return base + (long)((t + 3) % 3) * L.field; };
@@ -1221,7 +1276,7 @@ static int run_backward(Plan &p, int nshots, bool with_grad, bool with_illum)
     int launches = 0;
     float ms = 0;
     const auto key = std::make_tuple(1, nshots, with_grad ? 1 : 0, with_illum ? 1 : 0, 0);
-    if ((rc = timed_loop(p, ckpt ? nullptr : &key, enqueue, launches, ms))) return rc;
+    if ((rc = timed_loop(p, ckpt ? nullptr : &key, enqueue, launches, ms, true))) return rc;
     fill_stats(p, ms, nt - 2, nshots, with_grad ? 32.0 : 20.0, launches, true);
     p.rot_v_valid = true;
     return MIFWI_OK;
@@ -1358,6 +1413,7 @@ static int l2_misfit_gradient(Plan &p, int nshots, const void *wavelet, int per_
     p.stats.algorithmic_bytes = abytes;
     p.stats.gpointss = ms_total > 0 ? pts / (ms_total * 1e-3) / 1e9 : 0;
     p.stats.launches = launches;
+    p.timing_sum = true;   // asynchronous plans: kernel_ms = forward + backward once both are known
     return finish(p);
 }
 
@@ -1564,7 +1620,7 @@ static int tti_run(Plan &p, int nshots, int mode, int save)
     int launches = 0;
     float ms = 0;
     const auto key = std::make_tuple(4 + mode, nshots, save, 0, 0);
-    if ((rc = timed_loop(p, &key, enqueue, launches, ms))) return rc;
+    if ((rc = timed_loop(p, &key, enqueue, launches, ms, mode == 1))) return rc;
     fill_stats(p, ms, nt - 2, nshots, 2 * 20.0 + 6 * 4.0, launches, mode == 1);
     if (save) {
         p.tti_save_valid = true, p.tti_save_shots = nshots;
@@ -1679,7 +1735,7 @@ static int tti_gradient(Plan &p, int nshots, const void *residual, void *grad, i
     int launches = 0;
     float ms = 0;
     const auto key = std::make_tuple(7, nshots, 0, 0, 0);
-    if ((rc = timed_loop(p, &key, enqueue, launches, ms))) return rc;
+    if ((rc = timed_loop(p, &key, enqueue, launches, ms, true))) return rc;
     fill_stats(p, ms, nt - 2, nshots, 2 * 20.0 + 6 * 4.0 + 2 * 4.0 + 8.0, launches, true);
     p.tti_adj_valid = true;
     if ((rc = deliver_grid<T>(p, p.d_grad, grad, nshots, accumulate))) return rc;
@@ -1803,6 +1859,18 @@ using namespace mifwi;
 
 #define DISPATCH(expr_f32, expr_f64) (p.cfg.dtype == MIFWI_F64 ? (expr_f64) : (expr_f32))
 
+// Host containers (sparse tables, the graph cache) can throw std::bad_alloc: no exception crosses the C boundary.
+#define GUARDED(expr)                                                          \
+    try {                                                                      \
+        return (expr);                                                         \
+    } catch (const std::bad_alloc &) {                                         \
+        return fail(MIFWI_ENOMEM, "host allocation failed");                   \
+    } catch (const std::exception &e) {                                        \
+        return fail(MIFWI_EHIP, std::string("exception: ") + e.what());        \
+    } catch (...) {                                                            \
+        return fail(MIFWI_EHIP, "unknown exception");                          \
+    }
+
 extern "C" {
 
 int mifwi_version(void) { return MIFWI_VERSION; }
@@ -1811,11 +1879,7 @@ const char *mifwi_last_error(void) { return g_error.c_str(); }
 
 int mifwi_plan_create(const mifwi_config *cfg, mifwi_plan **out)
 {
-    try {
-        return create(cfg, out);
-    } catch (const std::exception &e) {
-        return fail(MIFWI_ENOMEM, std::string("exception: ") + e.what());
-    }
+    GUARDED(create(cfg, out));
 }
 
 int mifwi_plan_destroy(mifwi_plan *plan)
@@ -1829,7 +1893,12 @@ int mifwi_set_stream(mifwi_plan *plan, void *hip_stream)
 {
     PLAN_OR_FAIL(plan);
     MIFWI_HIP(hipStreamSynchronize(p.stream));
+    int rc = resolve_stats(p);   // pending loop times belong to the old stream
+    if (rc) return rc;
+    clear_graphs(p);
     if (p.own_stream && p.stream) (void)hipStreamDestroy(p.stream);
+    // a null handle is the legacy default stream: legal, but it cannot be captured, so time loops on it are
+    // launched kernel by kernel (see timed_loop)
     p.stream = reinterpret_cast<hipStream_t>(hip_stream);
     p.own_stream = false;
     return MIFWI_OK;
@@ -1839,18 +1908,14 @@ int mifwi_synchronize(mifwi_plan *plan)
 {
     PLAN_OR_FAIL(plan);
     MIFWI_HIP(hipStreamSynchronize(p.stream));
-    return MIFWI_OK;
+    return resolve_stats(p);
 }
 
 int mifwi_set_model(mifwi_plan *plan, const void *vp, const void *damp)
 {
     PLAN_OR_FAIL(plan);
     if (!vp) return fail(MIFWI_EINVAL, "vp is null");
-    try {
-        return DISPATCH(set_model<float>(p, vp, damp), set_model<double>(p, vp, damp));
-    } catch (const std::exception &e) {
-        return fail(MIFWI_ENOMEM, std::string("exception: ") + e.what());
-    }
+    GUARDED(DISPATCH(set_model<float>(p, vp, damp), set_model<double>(p, vp, damp)));
 }
 
 int mifwi_set_geometry(mifwi_plan *plan, int32_t nshots, const void *src_coords, const void *rec_coords,
@@ -1859,104 +1924,102 @@ int mifwi_set_geometry(mifwi_plan *plan, int32_t nshots, const void *src_coords,
     PLAN_OR_FAIL(plan);
     if (nshots < 1 || nshots > p.cfg.max_shots) return fail(MIFWI_EINVAL, "nshots must be in 1..max_shots");
     if ((p.cfg.nsrc > 0 && !src_coords) || (p.cfg.nrec > 0 && !rec_coords)) return fail(MIFWI_EINVAL, "null coordinates");
-    try {
-        return DISPATCH(set_geometry<float>(p, nshots, src_coords, rec_coords, rec_per_shot),
-                        set_geometry<double>(p, nshots, src_coords, rec_coords, rec_per_shot));
-    } catch (const std::exception &e) {
-        return fail(MIFWI_ENOMEM, std::string("exception: ") + e.what());
-    }
+    GUARDED(DISPATCH(set_geometry<float>(p, nshots, src_coords, rec_coords, rec_per_shot),
+                     set_geometry<double>(p, nshots, src_coords, rec_coords, rec_per_shot)));
 }
 
 int mifwi_forward(mifwi_plan *plan, int32_t nshots, const void *wavelet, int32_t wavelet_per_shot, void *rec_out,
                   int32_t save)
 {
     PLAN_OR_FAIL(plan);
-    return DISPATCH(forward<float>(p, nshots, wavelet, wavelet_per_shot, rec_out, save),
-                    forward<double>(p, nshots, wavelet, wavelet_per_shot, rec_out, save));
+    GUARDED(DISPATCH(forward<float>(p, nshots, wavelet, wavelet_per_shot, rec_out, save),
+                    forward<double>(p, nshots, wavelet, wavelet_per_shot, rec_out, save)));
 }
 
 int mifwi_born(mifwi_plan *plan, int32_t nshots, const void *wavelet, int32_t wavelet_per_shot, const void *dm,
                void *rec_out)
 {
     PLAN_OR_FAIL(plan);
-    return DISPATCH(born<float>(p, nshots, wavelet, wavelet_per_shot, dm, rec_out),
-                    born<double>(p, nshots, wavelet, wavelet_per_shot, dm, rec_out));
+    GUARDED(DISPATCH(born<float>(p, nshots, wavelet, wavelet_per_shot, dm, rec_out),
+                    born<double>(p, nshots, wavelet, wavelet_per_shot, dm, rec_out)));
 }
 
 int mifwi_adjoint(mifwi_plan *plan, int32_t nshots, const void *rec_in, void *srca_out)
 {
     PLAN_OR_FAIL(plan);
-    return DISPATCH(adjoint<float>(p, nshots, rec_in, srca_out), adjoint<double>(p, nshots, rec_in, srca_out));
+    GUARDED(DISPATCH(adjoint<float>(p, nshots, rec_in, srca_out), adjoint<double>(p, nshots, rec_in, srca_out)));
 }
 
 int mifwi_gradient(mifwi_plan *plan, int32_t nshots, const void *residual, void *grad, int32_t accumulate, void *illum)
 {
     PLAN_OR_FAIL(plan);
-    return DISPATCH(gradient<float>(p, nshots, residual, grad, accumulate, illum),
-                    gradient<double>(p, nshots, residual, grad, accumulate, illum));
+    GUARDED(DISPATCH(gradient<float>(p, nshots, residual, grad, accumulate, illum),
+                    gradient<double>(p, nshots, residual, grad, accumulate, illum)));
 }
 
 int mifwi_l2_misfit_gradient(mifwi_plan *plan, int32_t nshots, const void *wavelet, int32_t wavelet_per_shot,
                              const void *obs, double *fval, void *grad, void *illum, void *residual_out, void *syn_out)
 {
     PLAN_OR_FAIL(plan);
-    return DISPATCH(
+    GUARDED(DISPATCH(
         l2_misfit_gradient<float>(p, nshots, wavelet, wavelet_per_shot, obs, fval, grad, illum, residual_out, syn_out),
-        l2_misfit_gradient<double>(p, nshots, wavelet, wavelet_per_shot, obs, fval, grad, illum, residual_out, syn_out));
+        l2_misfit_gradient<double>(p, nshots, wavelet, wavelet_per_shot, obs, fval, grad, illum, residual_out, syn_out)));
 }
 
 int mifwi_tti_set_model(mifwi_plan *plan, const void *epsilon, const void *delta, const void *theta, const void *phi)
 {
     PLAN_OR_FAIL(plan);
-    return DISPATCH(tti_set_model<float>(p, epsilon, delta, theta, phi), tti_set_model<double>(p, epsilon, delta, theta, phi));
+    GUARDED(DISPATCH(tti_set_model<float>(p, epsilon, delta, theta, phi), tti_set_model<double>(p, epsilon, delta, theta, phi)));
 }
 
 int mifwi_tti_forward(mifwi_plan *plan, int32_t nshots, const void *wavelet, int32_t wavelet_per_shot, void *rec_out,
                       int32_t save)
 {
     PLAN_OR_FAIL(plan);
-    return DISPATCH(tti_forward<float>(p, nshots, wavelet, wavelet_per_shot, rec_out, save),
-                    tti_forward<double>(p, nshots, wavelet, wavelet_per_shot, rec_out, save));
+    GUARDED(DISPATCH(tti_forward<float>(p, nshots, wavelet, wavelet_per_shot, rec_out, save),
+                    tti_forward<double>(p, nshots, wavelet, wavelet_per_shot, rec_out, save)));
 }
 
 int mifwi_tti_adjoint(mifwi_plan *plan, int32_t nshots, const void *rec_in, void *srca_out)
 {
     PLAN_OR_FAIL(plan);
-    return DISPATCH(tti_adjoint<float>(p, nshots, rec_in, srca_out), tti_adjoint<double>(p, nshots, rec_in, srca_out));
+    GUARDED(DISPATCH(tti_adjoint<float>(p, nshots, rec_in, srca_out), tti_adjoint<double>(p, nshots, rec_in, srca_out)));
 }
 
 int mifwi_tti_born(mifwi_plan *plan, int32_t nshots, const void *wavelet, int32_t wavelet_per_shot, const void *dm,
                    void *rec_out)
 {
     PLAN_OR_FAIL(plan);
-    return DISPATCH(tti_born<float>(p, nshots, wavelet, wavelet_per_shot, dm, rec_out),
-                    tti_born<double>(p, nshots, wavelet, wavelet_per_shot, dm, rec_out));
+    GUARDED(DISPATCH(tti_born<float>(p, nshots, wavelet, wavelet_per_shot, dm, rec_out),
+                    tti_born<double>(p, nshots, wavelet, wavelet_per_shot, dm, rec_out)));
 }
 
 int mifwi_tti_gradient(mifwi_plan *plan, int32_t nshots, const void *residual, void *grad, int32_t accumulate)
 {
     PLAN_OR_FAIL(plan);
-    return DISPATCH(tti_gradient<float>(p, nshots, residual, grad, accumulate),
-                    tti_gradient<double>(p, nshots, residual, grad, accumulate));
+    GUARDED(DISPATCH(tti_gradient<float>(p, nshots, residual, grad, accumulate),
+                    tti_gradient<double>(p, nshots, residual, grad, accumulate)));
 }
 
 int mifwi_read_wavefield(mifwi_plan *plan, int32_t which, int32_t shot, int32_t first, int32_t count, void *out)
 {
     PLAN_OR_FAIL(plan);
-    return DISPATCH(read_wavefield<float>(p, which, shot, first, count, out),
-                    read_wavefield<double>(p, which, shot, first, count, out));
+    GUARDED(DISPATCH(read_wavefield<float>(p, which, shot, first, count, out),
+                    read_wavefield<double>(p, which, shot, first, count, out)));
 }
 
 int mifwi_write_wavefield(mifwi_plan *plan, int32_t shot, int32_t first, int32_t count, const void *in)
 {
     PLAN_OR_FAIL(plan);
-    return DISPATCH(write_wavefield<float>(p, shot, first, count, in), write_wavefield<double>(p, shot, first, count, in));
+    GUARDED(DISPATCH(write_wavefield<float>(p, shot, first, count, in), write_wavefield<double>(p, shot, first, count, in)));
 }
 
 int mifwi_get_stats(mifwi_plan *plan, mifwi_stats *out)
 {
     PLAN_OR_FAIL(plan);
     if (!out) return fail(MIFWI_EINVAL, "out is null");
+    int rc = resolve_stats(p);
+    if (rc) return rc;
     p.stats.device_bytes = p.device_bytes;
     *out = p.stats;
     return MIFWI_OK;

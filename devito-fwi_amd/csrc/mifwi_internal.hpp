@@ -97,7 +97,10 @@ struct Plan {
     size_t esize = 4;
     hipStream_t stream = nullptr;
     bool own_stream = false;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t ev[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};   // [forward | backward loop][begin | end]
+    bool timing_pending[2] = {false, false};   // the loop's events have been recorded but not read (MIFWI_FLAG_ASYNC)
+    int timing_last = 0;                       // loop whose time is stats.kernel_ms (0 forward, 1 backward)
+    bool timing_sum = false;                   // stats.kernel_ms of the last call = forward + backward loop
 
     void *m = nullptr, *eta = nullptr;       // haloed model fields
     bool have_model = false;
@@ -117,6 +120,9 @@ struct Plan {
     SparseSet src, rec;
 
     void *d_wavelet = nullptr;               // [max_shots][nt][nsrc]
+    void *d_wavelet_ck = nullptr;            // wavelets of the run that took the checkpoints (checkpointed plans only)
+    const void *wavelet_override = nullptr;  // while segments are recomputed: the wavelet the untiled kernels inject
+    bool ck_model_changed = false;           // mifwi_set_model ran after the checkpoints were taken
     void *d_rec = nullptr;                   // [max_shots][nt][nrec]   synthetic data
     void *d_res = nullptr;                   // [max_shots][nt][nrec]   adjoint source / residual
     void *d_srca = nullptr;                  // [max_shots][nt][nsrc]
@@ -445,7 +451,7 @@ __device__ inline void unpack_half2(unsigned u, float &a, float &b)
     a = f.x, b = f.y;
 }
 // per-shot scale of the half-precision saved levels from the injected source terms of the whole run
-int launch_save_scale(const Plan &p, const float *winj, long per_shot, int nshots, float *scale);
+int launch_save_scale(const Plan &p, const float *winj, const SparseSet &S, int nshots, float *scale);
 // haloed half-precision level(s) -> haloed float (divided by the shot's scale)
 int launch_half_to_float(const Plan &p, const void *src, float *dst, long n, const float *scale, int shot);
 

@@ -104,6 +104,17 @@ def _is_torch(x):
     return type(x).__module__.startswith("torch") and hasattr(x, "data_ptr")
 
 
+def _order_after_torch(x):
+    """A plan works on a stream of its own, which is not ordered with torch's streams.  Before a tensor's
+    memory is handed to the library, wait for the work torch has queued on its current stream of that
+    device: kernels still producing an input, or still reading an output buffer the call will overwrite.
+    (The other direction needs nothing: a call returns after the plan's stream has drained, and with
+    MIFWI_FLAG_ASYNC the caller synchronises the plan before touching results.)"""
+    if x.is_cuda:
+        import torch
+        torch.cuda.current_stream(x.device).synchronize()
+
+
 class Plan(object):
     """
     One discretised acquisition on one GPU: grid, stencil order, time axis, batch capacity.
@@ -150,6 +161,7 @@ class Plan(object):
             return None, None
         if _is_torch(x):
             assert x.is_contiguous()
+            _order_after_torch(x)
             return ctypes.c_void_p(x.data_ptr()), x
         a = np.ascontiguousarray(x, dtype=self.dtype)
         if shape is not None:
@@ -163,6 +175,7 @@ class Plan(object):
             x = np.empty(shape, dtype=dtype)
         if _is_torch(x):
             assert x.is_contiguous()
+            _order_after_torch(x)
             return ctypes.c_void_p(x.data_ptr()), x
         assert isinstance(x, np.ndarray) and x.flags.c_contiguous and x.dtype == dtype, "bad output array"
         assert x.size == int(np.prod(shape)), "bad output size"

@@ -99,6 +99,10 @@ class AcousticWaveSolver(object):
             out_u = DeviceTimeFunction('u', self.model.grid, nt if save else None, entry, None, which,
                                        time_order=2, space_order=self.space_order)
         token = entry.claim(which, out_u if u is None else None)
+        if save:
+            # saving runs may step on the rotating levels (storage 1) and stream copies into storage 0:
+            # a lazy wavefield of an earlier non-saving run must be fetched before that happens
+            entry.claim(1)
         data = entry.plan.forward(src.data, nshots=1, save=bool(save))
         rec.data[:] = data[0]
         if u is None:

@@ -80,6 +80,60 @@ def test_3d_full_grid_adjoint_pair_and_linearity(mifwi, so):
     plan.close()
 
 
+def test_3d_512_gradient_checkpoint_identity_and_jacobian_pair(mifwi):
+    """BASELINE config 4's grid (512^3 + sponge = 592^3, space order 8) with a time axis short enough for the
+    full save to fit (40 levels = 33 GB): the checkpointed gradient equals the fully saved one bit for bit, and
+    Born modelling and the gradient are an adjoint pair, <J dm, r> = <dm, J^T r>
+    (seismic/acoustic/operators.py:183-273).  Device tensors carry the 830 MB grid arrays."""
+    import torch
+    from seismic import Model
+    n, nbl, so, nt = 512, 40, 8, 40
+    vp = np.empty((n, n, n), dtype=np.float32)
+    vp[:] = np.linspace(1.5, 4.5, n, dtype=np.float32)[None, None, :]
+    vp += 0.2 * np.sin(np.arange(n, dtype=np.float32) * 0.05)[:, None, None]
+    model = Model(origin=(0., 0., 0.), spacing=(10., 10., 10.), shape=vp.shape, space_order=so, vp=vp, nbl=nbl,
+                  bcs="damp")
+    del vp
+    dt = float(model.critical_dt)
+    sp = model.grid.shape
+    rng = np.random.default_rng(17)
+    nrec = 256
+    src = np.array([[[2555.0, 2555.0, 2555.0]]], dtype=np.float32) + rng.random((1, 1, 3)).astype(np.float32) * 7
+    rec = (src[0, 0] + (rng.random((nrec, 3)) - 0.5) * 300.0).astype(np.float32)
+    s = rng.standard_normal((nt, 1)).astype(np.float32)
+    r = rng.standard_normal((1, nt, nrec)).astype(np.float32)
+    dev = torch.device("cuda")
+    grads = {}
+    for name, flags in (("full", 0), ("ckpt", mifwi.FLAG_CHECKPOINT)):
+        plan = mifwi.Plan(sp, model.spacing, model.grid.origin, so, nt, dt, 1, nrec, max_shots=1, flags=flags)
+        plan.set_model(model.vp.data, model.damp.data)
+        plan.set_geometry(src, rec)
+        plan.forward(s, save=True, want_rec=False)
+        g = torch.zeros((1,) + sp, dtype=torch.float32, device=dev)
+        il = torch.zeros_like(g)
+        plan.gradient(r, grad=g, illum=il)
+        grads[name] = (g, il)
+        if name == "full":
+            # dm: smooth-free random perturbation around the source, where both fields live within nt steps
+            dm = torch.zeros(sp, dtype=torch.float32, device=dev)
+            c = slice(296 - 24, 296 + 24)
+            dm[c, c, c] = 0.01 * torch.from_numpy(rng.standard_normal((48, 48, 48)).astype(np.float32)).to(dev)
+            jd = plan.born(s, dm)
+            assert np.abs(jd).max() > 0
+            lhs = _dot(jd, r)
+            rhs = float((dm.double() * g[0].double()).sum().item())
+            scale = max(float(np.linalg.norm(jd.astype(np.float64))) * float(np.linalg.norm(r.astype(np.float64))),
+                        float(dm.double().norm().item()) * float(g.double().norm().item()))
+            print("592^3 so=8: <J dm, r> = %.9e  <dm, J^T r> = %.9e  diff/scale = %.2e" %
+                  (lhs, rhs, abs(lhs - rhs) / scale))
+            assert abs(lhs - rhs) <= 1e-5 * scale and abs(lhs) > 1e-9 * scale
+            del dm
+        plan.close()
+    assert torch.equal(grads["full"][0], grads["ckpt"][0])
+    assert torch.equal(grads["full"][1], grads["ckpt"][1])
+    assert float(grads["full"][0].abs().max().item()) > 0
+
+
 def test_marmousi2_full_adjoint_pair_and_checkpoint_identity(mifwi):
     from seismic import Model
     shape, nbl, so = (340, 140), 40, 16

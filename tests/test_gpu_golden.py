@@ -45,3 +45,49 @@ def test_gpu_reproduces_golden(name):
     u_last = plan.read_wavefield(0, shot=0, first=nt - 1, count=1)
     assert np.isclose(np.linalg.norm(u_last.astype(np.float64)), float(g["u_last_norm"]), rtol=1e-5)
     plan.close()
+
+
+@pytest.mark.parametrize("batch,pos", [(4, 2), (32, 19), (32, 0)])
+def test_marmousi2_golden_shot_inside_a_batch(batch, pos):
+    """BASELINE config 3 runs 32 shots as one batch on one GPU and 4 shots per GPU on eight: the golden
+    Marmousi-II shot must come out the same from any slot of a 4- or 32-shot plan (the other slots hold
+    shots spread over the survey line as marmousi2_fwi.py:90-97 of the reference places them)."""
+    import mifwi
+    from oracle import oracle as orc
+    from seismic import Model
+    c, g = load("c3_marmousi2")
+    nbl, so = c["nbl"], c["so"]
+    dt, nt = float(g["dt"]), int(g["nt"])
+    kw = dict(origin=(0., 0.), spacing=c["spacing"], shape=c["true_vp"].shape, space_order=so, nbl=nbl, bcs="damp",
+              dt=c["dt"])
+    m_true, m_init = Model(vp=c["true_vp"], **kw), Model(vp=c["init_vp"], **kw)
+    tv = np.linspace(0.0, dt * (nt - 1), nt)
+    w = orc.ricker(float(g["f0"]), tv).astype(np.float32).reshape(nt, 1)
+    src = np.empty((batch, 1, 2), dtype=np.float32)
+    src[:, 0, 0] = np.linspace(0.0, m_true.domain_size[0], batch)
+    src[:, 0, 1] = 2 * c["spacing"][0]
+    src[pos, 0] = g["src"].reshape(2)
+    plan = mifwi.Plan(m_true.grid.shape, c["spacing"], m_true.grid.origin, so, nt, dt, 1, g["rec"].shape[0],
+                      max_shots=batch)
+    plan.set_geometry(src, g["rec"])
+    plan.set_model(m_true.vp.data, m_true.damp.data)
+    obs = plan.forward(w)
+    k = int(g["stride"])
+    assert rel_l2(obs[pos][:, ::k], g["obs"]) < 1e-5
+    plan.set_model(m_init.vp.data, m_init.damp.data)
+    out = plan.l2_misfit_gradient(w, obs, want_illum=True, want_syn=True)
+    assert rel_l2(out["syn"][pos][:, ::k], g["syn"]) < 1e-5
+    assert np.isclose(out["fval"][pos], float(g["fval"]), rtol=1e-5)
+    crop = (slice(nbl, -nbl), slice(nbl, -nbl))
+    assert rel_l2(out["grad"][pos][crop], g["grad"]) < 1e-4
+    assert rel_l2(out["illum"][pos][crop], g["illum"]) < 1e-4
+    # a shot's numbers do not depend on its neighbours in the batch: the same shot alone gives the same bits
+    single = mifwi.Plan(m_true.grid.shape, c["spacing"], m_true.grid.origin, so, nt, dt, 1, g["rec"].shape[0])
+    single.set_geometry(src[pos:pos + 1], g["rec"])
+    single.set_model(m_init.vp.data, m_init.damp.data)
+    one = single.l2_misfit_gradient(w, obs[pos:pos + 1], want_illum=True)
+    assert np.array_equal(one["grad"][0], out["grad"][pos])
+    assert np.array_equal(one["illum"][0], out["illum"][pos])
+    assert one["fval"][0] == out["fval"][pos]
+    single.close()
+    plan.close()
