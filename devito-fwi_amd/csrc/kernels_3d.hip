@@ -180,8 +180,8 @@ __global__ __launch_bounds__(TY *TZ / V, (MODE == 1 || MODE == 2 || MODE == 4 ? 
     const int chunk = t % a.nchunk;
     const int shot = t / a.nchunk;
     const int tile = tile_y * a.ntz + tile_z;
-    const int xa = chunk * a.xchunk;
-    const int xb = min(a.n0, xa + a.xchunk);
+    const int xa = a.x_lo + chunk * a.xchunk;
+    const int xb = min(a.x_hi, xa + a.xchunk);
     const int y0 = tile_y * TY, z0 = tile_z * TZ;
 
     const int ty = tid / TQ, tq = tid - ty * TQ;

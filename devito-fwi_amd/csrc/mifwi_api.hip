@@ -482,6 +482,9 @@ static int create(const mifwi_config *cfg, mifwi_plan **out)
         p->bpc_fwd = step3d_blocks_per_cu(p->L.R, false);
         p->bpc_grad = step3d_blocks_per_cu(p->L.R, true);
         if (const char *env = getenv("MIFWI_3D_NCHUNK")) p->nchunk_env = std::max(1, atoi(env));  // tuning experiments
+        if (const char *env = getenv("MIFWI_3D_SLAB")) p->slab_w = atoi(env);                      // tuning experiments
+        if (const char *env = getenv("MIFWI_3D_SLAB_CHUNKS")) p->slab_chunks = std::max(1, atoi(env));
+        if (p->slab_w > 0 && p->slab_w < 2 * p->L.R) p->slab_w = 2 * p->L.R;
     }
     // the tiled kernels address a field level with 32-bit byte offsets
     if (p->kind != 0 && (unsigned long long)p->L.field * 4ull >= (1ull << 32)) p->kind = 0;
@@ -762,6 +765,7 @@ static Step3DArgs base3d(const Plan &p, int nshots, bool grad)
     a.nty = p.ntx;
     a.ntz = p.ntz;
     choose_chunks(p, nshots, grad, a.nchunk, a.xchunk);
+    a.x_lo = 0, a.x_hi = p.L.n[0];
     a.nshots = nshots;
     a.nwork = p.ntx * p.ntz * a.nchunk * nshots;
     a.eta_zero = p.eta_zero;
@@ -825,7 +829,8 @@ struct BornTerm {
 template <typename T>
 static int forward_step(Plan &p, const LoopCtx<T> &c, const T *cur, const T *old, T *out, long shot_stride, int time,
                         bool interp, int &launches, bool inject = true, T *copy = nullptr, long copy_stride = 0,
-                        const BornTerm<T> *born = nullptr, T *copy_prev = nullptr)
+                        const BornTerm<T> *born = nullptr, T *copy_prev = nullptr, int x_lo = -1, int x_hi = -1,
+                        int x_chunks = 1)
 {
     int rc;
     if (p.kind == 1) {
@@ -847,6 +852,12 @@ static int forward_step(Plan &p, const LoopCtx<T> &c, const T *cur, const T *old
     if (p.kind == 2) {
         Step3DArgs a = c.a3;
         a.shot_stride = shot_stride;
+        if (x_lo >= 0) {   // one slab of planes only (2.5-D kernel)
+            a.x_lo = x_lo, a.x_hi = x_hi;
+            a.xchunk = (x_hi - x_lo + x_chunks - 1) / x_chunks;
+            a.nchunk = (x_hi - x_lo + a.xchunk - 1) / a.xchunk;
+            a.nwork = a.nty * a.ntz * a.nchunk * a.nshots;
+        }
         if (inject) set_inject3(a, p.src, p);
         if (interp) set_interp3(a, p.rec, p.d_rec);
         a.cur = (const float *)cur, a.old = (const float *)old, a.out = (float *)out, a.time = time;
@@ -1133,12 +1144,43 @@ static int run_forward(Plan &p, int nshots, int save)
     const bool in_saved = full_save && !copy_save;
     auto lvl = [&](int t) { return in_saved ? base + (long)t * sv_lstride : base + (long)(t % 3) * L.field; };
     const bool ckpt = save && !full_save;
+    // Two steps per sweep over the grid (2.5-D kernel, nothing saved): x is cut into slabs of slab_w planes and
+    // the second step follows the first one slab behind, so that what it reads -- the level the first step has
+    // just written, the level before it and the coefficients -- is still in the 256 MB last-level cache.
+    const int slab_w = (p.kind == 2 && !save) ? p.slab_w : 0;
     if (ckpt) {
         MIFWI_HIP(hipMemcpyAsync(p.d_wavelet_ck, p.d_wavelet, (size_t)nshots * nt * std::max(1, p.cfg.nsrc) * sizeof(T),
                                  hipMemcpyDeviceToDevice, p.stream));
         p.ck_model_changed = false;
     }
+    auto enqueue_slabs = [&](int &launches) -> int {
+        const int n0 = L.n[0], R = L.R, W = slab_w, S = (n0 + W - 1) / W;
+        int r;
+        for (int time = 1; time <= nt - 2; time += 2) {
+            if (time + 1 > nt - 2) {   // odd number of steps: the last one alone
+                if ((r = forward_step<T>(p, ctx, lvl(time), lvl(time - 1), lvl(time + 1), shot_stride, time, true, launches)))
+                    return r;
+                break;
+            }
+            for (int sl = 0; sl < S; ++sl) {
+                // first step on planes [sl W, (sl+1) W): receivers sample u[time], complete since the last sweep
+                if ((r = forward_step<T>(p, ctx, lvl(time), lvl(time - 1), lvl(time + 1), shot_stride, time, sl == 0,
+                                         launches, true, nullptr, 0, nullptr, nullptr, sl * W, std::min(n0, (sl + 1) * W),
+                                         p.slab_chunks)))
+                    return r;
+                // second step R planes behind; it overwrites u[time-1] only where the first step is done with it.
+                // Receivers sample u[time+1], which is complete once the last slab of the first step has run.
+                const int lo = std::max(0, sl * W - R), hi = (sl == S - 1) ? n0 : (sl + 1) * W - R;
+                if (hi > lo &&
+                    (r = forward_step<T>(p, ctx, lvl(time + 1), lvl(time), lvl(time + 2), shot_stride, time + 1, sl == S - 1,
+                                         launches, true, nullptr, 0, nullptr, nullptr, lo, hi, p.slab_chunks)))
+                    return r;
+            }
+        }
+        return MIFWI_OK;
+    };
     auto enqueue = [&](int &launches) -> int {
+        if (slab_w > 0) return enqueue_slabs(launches);
         for (int time = 1; time <= nt - 2; ++time) {
             if (ckpt && (time - 1) % p.ck_K == 0) {
                 // keep the two levels that enter this segment: u[time-1], u[time]
@@ -1165,7 +1207,7 @@ static int run_forward(Plan &p, int nshots, int save)
     };
     int launches = 0;
     float ms = 0;
-    const auto key = std::make_tuple(0, nshots, save ? 1 : 0, 0, 0);
+    const auto key = std::make_tuple(0, nshots, save ? 1 : 0, slab_w, 0);
     if ((rc = timed_loop(p, ckpt ? nullptr : &key, enqueue, launches, ms))) return rc;
     fill_stats(p, ms, nt - 2, nshots, 20.0, launches, false);
     if (save) {

@@ -160,6 +160,7 @@ struct Plan {
     int xchunk = 0, nchunk = 0;
     int ncu = 256, bpc_fwd = 2, bpc_grad = 2;  // CUs and resident 2.5-D blocks per CU (plain / gradient)
     int nchunk_env = 0;
+    int slab_w = 0, slab_chunks = 1;   // two-step sweeps of the 2.5-D kernel: planes per slab (0 = off), chunks per slab
     unsigned char *eta_zero = nullptr;  // 2.5-D kernel: [tile][n0] flags of sponge-free patches
     int vec3d = 0;  // points per thread of the 2.5-D kernel: 0 = by stencil radius, else 2 or 4
     int vec2d = 4;      // points per thread of the tiled 2-D kernel (2: experiment, 32 x 32 tiles only)
@@ -383,6 +384,7 @@ struct Step3DArgs {
     int n0, n1, n2;
     long s0, s1, off0;
     int nty, ntz, nchunk, xchunk, nwork, nshots;
+    int x_lo, x_hi;   // planes this launch updates: x_lo <= x < x_hi, split into nchunk chunks of xchunk planes
     const unsigned char *eta_zero;   // [tile][n0] sponge-free flags, or null
     // gradient (um == nullptr: plain propagation)
     const float *um, *uc, *up;
