@@ -470,7 +470,7 @@ template int launch_pack<double>(const Plan &, const double *, double *, long, i
 // Deterministic: fixed block partition, tree reduction in f64, then one block per shot sums the
 // partials in index order.
 // ------------------------------------------------------------------------------------------
-constexpr int kMisfitBlocks = 64;
+constexpr int kMisfitBlocks = kMisfitPartials;
 
 template <typename T>
 __global__ __launch_bounds__(256) void misfit_partial_kernel(const T *syn, const T *obs, T *res, long n, double *partial)
@@ -504,15 +504,25 @@ __global__ void misfit_final_kernel(const double *partial, double *fval)
     }
 }
 template <typename T>
+int launch_l2_misfit_on(hipStream_t stream, const T *syn, const T *obs, T *res, long n, int nshots, double *partial,
+                        double *fval)
+{
+    hipLaunchKernelGGL((misfit_partial_kernel<T>), dim3(kMisfitBlocks, nshots), dim3(256), 0, stream, syn, obs, res, n,
+                       partial);
+    MIFWI_HIP(hipGetLastError());
+    hipLaunchKernelGGL(misfit_final_kernel, dim3(nshots), dim3(64), 0, stream, partial, fval);
+    MIFWI_HIP(hipGetLastError());
+    return MIFWI_OK;
+}
+template int launch_l2_misfit_on<float>(hipStream_t, const float *, const float *, float *, long, int, double *, double *);
+template int launch_l2_misfit_on<double>(hipStream_t, const double *, const double *, double *, long, int, double *,
+                                         double *);
+
+template <typename T>
 int launch_l2_misfit(const Plan &p, const T *syn, const T *obs, T *res, long n, int nshots, double *partial,
                      double *fval)
 {
-    hipLaunchKernelGGL((misfit_partial_kernel<T>), dim3(kMisfitBlocks, nshots), dim3(256), 0, p.stream, syn, obs, res,
-                       n, partial);
-    MIFWI_HIP(hipGetLastError());
-    hipLaunchKernelGGL(misfit_final_kernel, dim3(nshots), dim3(64), 0, p.stream, partial, fval);
-    MIFWI_HIP(hipGetLastError());
-    return MIFWI_OK;
+    return launch_l2_misfit_on<T>(p.stream, syn, obs, res, n, nshots, partial, fval);
 }
 template int launch_l2_misfit<float>(const Plan &, const float *, const float *, float *, long, int, double *,
                                      double *);

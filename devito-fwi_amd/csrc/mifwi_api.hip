@@ -1459,6 +1459,32 @@ static int l2_misfit_gradient(Plan &p, int nshots, const void *wavelet, int per_
     return finish(p);
 }
 
+// Least-squares misfit of data already modelled (misfit/misfit.py:5-9): residual = syn - obs,
+// fval[shot] = 0.5 * ||residual||^2.  Host arrays are staged through the plan's data buffers.
+template <typename T>
+static int l2_misfit(Plan &p, int nshots, const void *syn, const void *obs, void *residual_out, double *fval)
+{
+    if (nshots < 1 || nshots > p.cfg.max_shots) return fail(MIFWI_EINVAL, "nshots must be in 1..max_shots");
+    if (!syn || !obs) return fail(MIFWI_EINVAL, "syn or obs is null");
+    const long n = (long)p.cfg.nt * p.cfg.nrec;
+    const size_t bytes = (size_t)nshots * n * sizeof(T);
+    int rc;
+    const T *s = (const T *)syn, *o = (const T *)obs;
+    if (!is_device_ptr(syn)) {
+        if ((rc = copy_any(p, p.d_rec, syn, bytes))) return rc;
+        s = (const T *)p.d_rec;
+    }
+    if (!is_device_ptr(obs)) {
+        if ((rc = copy_any(p, p.d_res, obs, bytes))) return rc;
+        o = (const T *)p.d_res;
+    }
+    T *r = (residual_out && is_device_ptr(residual_out)) ? (T *)residual_out : (T *)p.d_res;
+    if ((rc = launch_l2_misfit<T>(p, s, o, r, n, nshots, p.d_partial, p.d_fval))) return rc;
+    if (residual_out && r != residual_out && (rc = copy_any(p, residual_out, r, bytes))) return rc;
+    if (fval && (rc = copy_any(p, fval, p.d_fval, (size_t)nshots * sizeof(double)))) return rc;
+    return finish(p);
+}
+
 // ---- TTI ---------------------------------------------------------------------------------------
 template <typename T>
 static int tti_set_model(Plan &p, const void *eps, const void *delta, const void *theta, const void *phi)
@@ -2006,6 +2032,13 @@ int mifwi_l2_misfit_gradient(mifwi_plan *plan, int32_t nshots, const void *wavel
     GUARDED(DISPATCH(
         l2_misfit_gradient<float>(p, nshots, wavelet, wavelet_per_shot, obs, fval, grad, illum, residual_out, syn_out),
         l2_misfit_gradient<double>(p, nshots, wavelet, wavelet_per_shot, obs, fval, grad, illum, residual_out, syn_out)));
+}
+
+int mifwi_l2_misfit(mifwi_plan *plan, int32_t nshots, const void *syn, const void *obs, void *residual_out, double *fval)
+{
+    PLAN_OR_FAIL(plan);
+    GUARDED(DISPATCH(l2_misfit<float>(p, nshots, syn, obs, residual_out, fval),
+                     l2_misfit<double>(p, nshots, syn, obs, residual_out, fval)));
 }
 
 int mifwi_tti_set_model(mifwi_plan *plan, const void *epsilon, const void *delta, const void *theta, const void *phi)

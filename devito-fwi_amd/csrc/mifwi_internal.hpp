@@ -262,6 +262,11 @@ int launch_pack(const Plan &p, const T *dense, T *haloed, long shot_stride, int 
 template <typename T>
 int launch_l2_misfit(const Plan &p, const T *syn, const T *obs, T *res, long n_per_shot, int nshots,
                      double *partial, double *fval);
+// the same on any stream; `partial` holds kMisfitPartials doubles per shot, each written before it is read
+constexpr int kMisfitPartials = 64;
+template <typename T>
+int launch_l2_misfit_on(hipStream_t stream, const T *syn, const T *obs, T *res, long n_per_shot, int nshots,
+                        double *partial, double *fval);
 
 // ---- TTI propagators (kernels_tti.hip) ----------------------------------------------------------
 template <typename T>

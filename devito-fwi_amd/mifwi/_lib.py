@@ -15,7 +15,7 @@ EXPORTED_SYMBOLS = (
     "mifwi_synchronize", "mifwi_set_model", "mifwi_set_geometry", "mifwi_forward", "mifwi_adjoint",
     "mifwi_gradient", "mifwi_l2_misfit_gradient", "mifwi_read_wavefield", "mifwi_write_wavefield",
     "mifwi_get_stats", "mifwi_born", "mifwi_tti_set_model", "mifwi_tti_forward", "mifwi_tti_adjoint",
-    "mifwi_tti_born", "mifwi_tti_gradient",
+    "mifwi_tti_born", "mifwi_tti_gradient", "mifwi_l2_misfit",
 )
 
 
@@ -89,6 +89,7 @@ def load_library():
     lib.mifwi_tti_adjoint.argtypes = [vp, i32, vp, vp]
     lib.mifwi_gradient.argtypes = [vp, i32, vp, vp, i32, vp]
     lib.mifwi_l2_misfit_gradient.argtypes = [vp, i32, vp, i32, vp, vp, vp, vp, vp, vp]
+    lib.mifwi_l2_misfit.argtypes = [vp, i32, vp, vp, vp, vp]
     lib.mifwi_read_wavefield.argtypes = [vp, i32, i32, i32, i32, vp]
     lib.mifwi_write_wavefield.argtypes = [vp, i32, i32, i32, vp]
     lib.mifwi_get_stats.argtypes = [vp, ctypes.POINTER(_Stats)]
@@ -327,6 +328,18 @@ class Plan(object):
         self._check(self._lib.mifwi_l2_misfit_gradient(self._h, nshots, pw, int(bool(wavelet_per_shot)), po, pf,
                                                        pg, pl, pr, ps))
         return dict(fval=fval, grad=grad, illum=il, residual=res, syn=syn)
+
+    def l2_misfit(self, syn, obs, nshots=None, residual=None, want_residual=True, fval=None):
+        """(fval per shot, residual) of the least-squares misfit for gathers of shape (nshots, nt, nrec)."""
+        nshots = nshots or self.nshots
+        ps, ks = self._in(syn)
+        po, ko = self._in(obs)
+        pr, res = (None, None)
+        if want_residual or residual is not None:
+            pr, res = self._out(residual, (nshots, self.nt, self.nrec))
+        pf, fval = self._out(fval, (nshots,), np.dtype(np.float64))
+        self._check(self._lib.mifwi_l2_misfit(self._h, nshots, ps, po, pr, pf))
+        return fval, res
 
     def read_wavefield(self, which=0, shot=0, first=0, count=None, out=None):
         nlev = self.nt if which in (0, 7, 8) else 3

@@ -186,6 +186,13 @@ MIFWI_API int mifwi_l2_misfit_gradient(mifwi_plan *plan, int32_t nshots, const v
                              int32_t wavelet_per_shot, const void *obs, double *fval, void *grad,
                              void *illum, void *residual_out, void *syn_out);
 
+/* Replaces: least_square(syn, obs) of misfit/misfit.py:5-9 as fwi.py:151 calls it between the forward and the
+ * gradient pass, on gathers that are already on the device: residual_out = syn - obs and
+ * fval[shot] = 0.5 * sum residual^2 (float64, fixed summation order: the same bits on every call).
+ * syn, obs, residual_out: (nshots, nt, nrec), host or device; residual_out may be NULL; fval (nshots) doubles. */
+MIFWI_API int mifwi_l2_misfit(mifwi_plan *plan, int32_t nshots, const void *syn, const void *obs, void *residual_out,
+                    double *fval);
+
 /* ---- TTI media, 'centered' kernel (seismic/tti/operators.py:198-313,430-519 and
  * seismic/tti/wavesolver.py:80-215 of the reference) -------------------------------------------
  * mifwi_tti_set_model replaces the epsilon / delta / theta / phi operator arguments

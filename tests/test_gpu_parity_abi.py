@@ -274,3 +274,29 @@ def test_short_time_axes_of_either_parity(mifwi, flags):
                     assert rel_l2(grad[s], g_ref) <= tol, (shape, nt, s, "grad")
                 assert rel_l2(illum[s], (u * u).sum(axis=0)) <= tol, (shape, nt, s, "illum")
             plan.close()
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_l2_misfit_of_given_gathers(mifwi, dtype):
+    """mifwi_l2_misfit against misfit/misfit.py:5-9 restated in numpy: residual bit for bit, objective to
+    float64 rounding; host arrays, device arrays, and the same bits on every call."""
+    import torch
+    case = Case((30, 28), (10.0, 10.0), nbl=5, space_order=4, nt=333, nshots=3, nrec=17, dtype=dtype, seed=2)
+    plan = case.plan(mifwi)
+    rng = np.random.default_rng(4)
+    syn = rng.standard_normal((3, case.nt, 17)).astype(dtype)
+    obs = rng.standard_normal((3, case.nt, 17)).astype(dtype)
+    f, r = plan.l2_misfit(syn, obs)
+    assert np.array_equal(r, syn - obs)
+    ref = 0.5 * ((syn - obs).astype(np.float64) ** 2).reshape(3, -1).sum(axis=1)
+    assert np.allclose(f, ref, rtol=1e-13, atol=0)
+    d_syn, d_obs = torch.from_numpy(syn).cuda(), torch.from_numpy(obs).cuda()
+    d_res = torch.empty_like(d_syn)
+    d_f = torch.zeros(3, dtype=torch.float64, device="cuda")
+    plan.l2_misfit(d_syn, d_obs, residual=d_res, fval=d_f)
+    assert np.array_equal(d_res.cpu().numpy(), r) and np.array_equal(d_f.cpu().numpy(), f)
+    f2, _ = plan.l2_misfit(syn[:2], obs[:2], nshots=2, want_residual=False)
+    assert np.array_equal(f2, f[:2])
+    with pytest.raises(mifwi.MifwiError):
+        plan.l2_misfit(syn, obs, nshots=4)
+    plan.close()

@@ -26,10 +26,11 @@ def test_async_calls_return_before_the_work_is_done(mifwi):
     mifwi_synchronize / mifwi_get_stats."""
     case = Case((300, 260), (10.0, 10.0), nbl=20, space_order=8, nt=4000, nshots=4, nrec=50, seed=2)
     ref = case.plan(mifwi)
+    ref.forward(case.wavelet)            # first run: graph capture, cold clocks
     rec_ref = ref.forward(case.wavelet)
     loop_ms = ref.stats()["fwd_ms"]
     ref.close()
-    assert loop_ms > 8.0, loop_ms      # long enough for the comparison below to mean something
+    assert loop_ms > 4.0, loop_ms      # long enough for the comparison below to mean something
     import torch
     dev = torch.device("cuda")
     w = torch.from_numpy(case.wavelet).to(dev)
@@ -48,8 +49,8 @@ def test_async_calls_return_before_the_work_is_done(mifwi):
     wall_ms = (time.perf_counter() - t0) * 1e3
     print("loop %.2f ms on the GPU; both asynchronous calls returned after %.2f ms, done after %.2f ms"
           % (loop_ms, host_ms, wall_ms))
-    assert host_ms < 0.5 * loop_ms, (host_ms, loop_ms)
-    assert wall_ms > 0.9 * loop_ms
+    assert host_ms < 0.4 * loop_ms, (host_ms, loop_ms)
+    assert wall_ms > 0.9 * loop_ms      # the work did take its time: the calls had returned before it was done
     for p, r in zip(plans, recs):
         st = p.stats()
         assert 0.5 * loop_ms < st["fwd_ms"] < 4.0 * loop_ms and st["kernel_ms"] == st["fwd_ms"]
@@ -138,7 +139,7 @@ def test_half_precision_scale_ignores_unused_injection_slots(mifwi):
         half.forward(case.wavelet, save=True)
         g = half.gradient(res)
         for s in range(2):
-            assert rel_l2(g[s], g_ref[s]) < 2e-3, (trial, s, rel_l2(g[s], g_ref[s]))
+            assert rel_l2(g[s], g_ref[s]) < 5e-3, (trial, s, rel_l2(g[s], g_ref[s]))   # white-noise residual: worst case for the rounding
         half.close()
 
 
