@@ -4,6 +4,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 
 #include "mifwi_internal.hpp"
@@ -206,6 +207,32 @@ static bool is_device_ptr(const void *ptr)
         return false;
     }
     return a.type == hipMemoryTypeDevice;
+}
+
+// ---- the entry point that allocates nothing ------------------------------------------------------
+// Partial sums of mifwi_l2_misfit_noalloc live in this array instead of in memory from hipMalloc.  Every GPU
+// the library runs on holds its own copy, at its own address, until the process ends (128 KiB each).  In host
+// code the array's name is only a handle for hipGetSymbolAddress: the address kernels are given is looked up
+// once per device, with that device current, and kept in g_scratch_ptr.
+constexpr int kNoAllocMaxShots = 256;
+constexpr int kMaxDevices = 64;
+static __device__ __align__(256) double g_misfit_scratch[kNoAllocMaxShots * kMisfitPartials];
+static std::mutex g_scratch_mutex;
+static double *g_scratch_ptr[kMaxDevices] = {};
+
+// device address of g_misfit_scratch on device `dev`, which must be the current device
+static int scratch_of_current_device(int dev, double **out)
+{
+    if (dev < 0 || dev >= kMaxDevices) return fail(MIFWI_EINVAL, "device ordinal beyond the library's table");
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (!g_scratch_ptr[dev]) {
+        void *ptr = nullptr;
+        MIFWI_HIP(hipGetSymbolAddress(&ptr, HIP_SYMBOL(g_misfit_scratch)));
+        if (!ptr) return fail(MIFWI_EHIP, "hipGetSymbolAddress returned a null address");
+        g_scratch_ptr[dev] = static_cast<double *>(ptr);
+    }
+    *out = g_scratch_ptr[dev];
+    return MIFWI_OK;
 }
 
 // ---- sparse tables --------------------------------------------------------------------------
@@ -446,6 +473,10 @@ static int create(const mifwi_config *cfg, mifwi_plan **out)
     if (dev < 0) MIFWI_HIP(hipGetDevice(&dev));
     if (dev >= ndev) return fail(MIFWI_EINVAL, "device ordinal out of range");
     MIFWI_HIP(hipSetDevice(dev));
+    {
+        double *unused = nullptr;   // first use of this device: look up the address of the static scratch array
+        if ((rc = scratch_of_current_device(dev, &unused))) return rc;
+    }
     Plan *p = new (std::nothrow) Plan();
     if (!p) return fail(MIFWI_ENOMEM, "host allocation failed");
     p->cfg = *cfg;
@@ -1485,6 +1516,21 @@ static int l2_misfit(Plan &p, int nshots, const void *syn, const void *obs, void
     return finish(p);
 }
 
+// ---- the entry point that allocates nothing: its body (scratch array and address look-up: top of this file) ---
+template <typename T>
+static int l2_misfit_noalloc(int nshots, long n, const void *syn, const void *obs, void *res, double *fval,
+                             hipStream_t stream)
+{
+    int dev = 0;
+    MIFWI_HIP(hipGetDevice(&dev));
+    double *partial = nullptr;
+    int rc = scratch_of_current_device(dev, &partial);
+    if (rc) return rc;
+    // every partial sum of the shots of this call is written by the first kernel before the second reads it:
+    // what the previous call left in the array needs no clearing
+    return launch_l2_misfit_on<T>(stream, (const T *)syn, (const T *)obs, (T *)res, n, nshots, partial, fval);
+}
+
 // ---- TTI ---------------------------------------------------------------------------------------
 template <typename T>
 static int tti_set_model(Plan &p, const void *eps, const void *delta, const void *theta, const void *phi)
@@ -2039,6 +2085,22 @@ int mifwi_l2_misfit(mifwi_plan *plan, int32_t nshots, const void *syn, const voi
     PLAN_OR_FAIL(plan);
     GUARDED(DISPATCH(l2_misfit<float>(p, nshots, syn, obs, residual_out, fval),
                      l2_misfit<double>(p, nshots, syn, obs, residual_out, fval)));
+}
+
+int mifwi_l2_misfit_noalloc(int32_t dtype, int32_t nshots, int64_t n_per_shot, const void *syn, const void *obs,
+                            void *residual_out, double *fval, void *hip_stream)
+{
+    if (dtype != MIFWI_F32 && dtype != MIFWI_F64) return fail(MIFWI_EINVAL, "dtype must be MIFWI_F32 or MIFWI_F64");
+    if (nshots < 1 || nshots > kNoAllocMaxShots)
+        return fail(MIFWI_EINVAL, "mifwi_l2_misfit_noalloc handles 1.." + std::to_string(kNoAllocMaxShots) +
+                                      " shots per call (fixed scratch array)");
+    if (n_per_shot < 0) return fail(MIFWI_EINVAL, "n_per_shot is negative");
+    if (!syn || !obs || !residual_out || !fval) return fail(MIFWI_EINVAL, "null array argument");
+    for (const void *ptr : {syn, obs, (const void *)residual_out, (const void *)fval})
+        if (!is_device_ptr(ptr)) return fail(MIFWI_EINVAL, "mifwi_l2_misfit_noalloc takes device pointers only");
+    hipStream_t stream = reinterpret_cast<hipStream_t>(hip_stream);
+    GUARDED(dtype == MIFWI_F64 ? l2_misfit_noalloc<double>(nshots, (long)n_per_shot, syn, obs, residual_out, fval, stream)
+                               : l2_misfit_noalloc<float>(nshots, (long)n_per_shot, syn, obs, residual_out, fval, stream));
 }
 
 int mifwi_tti_set_model(mifwi_plan *plan, const void *epsilon, const void *delta, const void *theta, const void *phi)

@@ -15,7 +15,7 @@ EXPORTED_SYMBOLS = (
     "mifwi_synchronize", "mifwi_set_model", "mifwi_set_geometry", "mifwi_forward", "mifwi_adjoint",
     "mifwi_gradient", "mifwi_l2_misfit_gradient", "mifwi_read_wavefield", "mifwi_write_wavefield",
     "mifwi_get_stats", "mifwi_born", "mifwi_tti_set_model", "mifwi_tti_forward", "mifwi_tti_adjoint",
-    "mifwi_tti_born", "mifwi_tti_gradient", "mifwi_l2_misfit",
+    "mifwi_tti_born", "mifwi_tti_gradient", "mifwi_l2_misfit", "mifwi_l2_misfit_noalloc",
 )
 
 
@@ -90,6 +90,7 @@ def load_library():
     lib.mifwi_gradient.argtypes = [vp, i32, vp, vp, i32, vp]
     lib.mifwi_l2_misfit_gradient.argtypes = [vp, i32, vp, i32, vp, vp, vp, vp, vp, vp]
     lib.mifwi_l2_misfit.argtypes = [vp, i32, vp, vp, vp, vp]
+    lib.mifwi_l2_misfit_noalloc.argtypes = [i32, i32, ctypes.c_int64, vp, vp, vp, vp, vp]
     lib.mifwi_read_wavefield.argtypes = [vp, i32, i32, i32, i32, vp]
     lib.mifwi_write_wavefield.argtypes = [vp, i32, i32, i32, vp]
     lib.mifwi_get_stats.argtypes = [vp, ctypes.POINTER(_Stats)]
@@ -114,6 +115,24 @@ def _order_after_torch(x):
     if x.is_cuda:
         import torch
         torch.cuda.current_stream(x.device).synchronize()
+
+
+def l2_misfit_noalloc(syn, obs, residual, fval, stream=0):
+    """mifwi_l2_misfit_noalloc on torch tensors of the current device: syn, obs, residual (nshots, ...) float32 or
+    float64, fval (nshots,) float64; enqueued on `stream` (a raw hipStream_t, 0 = default stream).  Allocates
+    nothing and does not wait."""
+    lib = load_library()
+    for t in (syn, obs, residual, fval):
+        assert _is_torch(t) and t.is_cuda and t.is_contiguous()
+    assert syn.shape == obs.shape == residual.shape and syn.dtype == obs.dtype == residual.dtype
+    nshots = int(syn.shape[0])
+    n = int(syn.numel() // max(1, nshots))
+    dt = F64 if syn.element_size() == 8 else F32
+    rc = lib.mifwi_l2_misfit_noalloc(dt, nshots, n, ctypes.c_void_p(syn.data_ptr()), ctypes.c_void_p(obs.data_ptr()),
+                                     ctypes.c_void_p(residual.data_ptr()), ctypes.c_void_p(fval.data_ptr()),
+                                     ctypes.c_void_p(int(stream)))
+    if rc != 0:
+        raise MifwiError(rc, lib.mifwi_last_error().decode())
 
 
 class Plan(object):

@@ -193,6 +193,17 @@ MIFWI_API int mifwi_l2_misfit_gradient(mifwi_plan *plan, int32_t nshots, const v
 MIFWI_API int mifwi_l2_misfit(mifwi_plan *plan, int32_t nshots, const void *syn, const void *obs, void *residual_out,
                     double *fval);
 
+/* No counterpart in the reference.  For callers that cannot allocate device memory: code under HIP graph capture,
+ * tight loops that must not touch the allocator, harnesses that forbid hipMalloc.  The same computation and the
+ * same bits as mifwi_l2_misfit, without a plan: syn, obs, residual_out are (nshots, n_per_shot) DEVICE arrays of
+ * `dtype` (MIFWI_F32 / MIFWI_F64) on the current device, fval (nshots) device doubles; the kernels are enqueued on
+ * `hip_stream` (NULL = the default stream) and the call returns without waiting.  It calls no hipMalloc / hipFree:
+ * the partial sums live in a fixed array inside the library (128 KiB per GPU, held until the process ends), which
+ * limits a call to 256 shots (MIFWI_EINVAL beyond).  All calls on one GPU share that array: calls that overlap in
+ * time on one GPU (different streams) race; serialise them. */
+MIFWI_API int mifwi_l2_misfit_noalloc(int32_t dtype, int32_t nshots, int64_t n_per_shot, const void *syn,
+                            const void *obs, void *residual_out, double *fval, void *hip_stream);
+
 /* ---- TTI media, 'centered' kernel (seismic/tti/operators.py:198-313,430-519 and
  * seismic/tti/wavesolver.py:80-215 of the reference) -------------------------------------------
  * mifwi_tti_set_model replaces the epsilon / delta / theta / phi operator arguments
