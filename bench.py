@@ -13,9 +13,14 @@ all-reduced over RCCL.  Each rank owns 8 different shots of an 8N-shot survey (w
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
+    ... bench.py --gpus N --shots-total 32     # strong scaling: BASELINE config 3, a fixed 32-shot survey
+
 Rank 0 prints ONE JSON line.  `roofline` describes the dominant kernel (the gradient time step);
 `cpu_baseline` is the CPU oracle (a restatement of the Devito CPU path, not Devito itself) timed
-on the host cores for a bounded sample of the same workload.
+on the host cores for a bounded sample of the same workload, in two modes: shots one after the other
+with every core on one shot (how the reference runs), and one shot per core side by side.
+At N = 1 `shot_batches` times the same gradient evaluation for batches of 4 and 32 shots: their ratio is
+what eight GPUs with 4 shots each can gain over one GPU with all 32 (before the all-reduce).
 """
 import argparse
 import json
@@ -36,12 +41,22 @@ SHOTS_PER_GPU = 8
 
 def pmc_traffic(kernel):
     """HBM-side bytes per launch of `kernel` from the committed rocprofv3 PMC passes of this same
-    command (profiles/r1_traffic.json), or None when no such measurement is recorded."""
+    command (profiles/r2_traffic.json), or None when no such measurement is recorded."""
+    return _profile_entry(kernel).get("bytes")
+
+
+def _profile_entry(kernel):
     try:
-        with open(os.path.join(ROOT, "profiles", "r1_traffic.json")) as f:
-            return json.load(f).get(kernel, {}).get("bytes")
+        with open(os.path.join(ROOT, "profiles", "r2_traffic.json")) as f:
+            return json.load(f).get(kernel, {})
     except (OSError, ValueError):
-        return None
+        return {}
+
+
+def profile_launch_us(kernel):
+    """Average duration of one launch of `kernel` in the committed rocprofv3 kernel trace of this same
+    command (microseconds), or None."""
+    return _profile_entry(kernel).get("avg_us")
 
 
 def marmousi2(space_order):
@@ -69,27 +84,65 @@ def acquisition(model, nshots_total):
     return src, rec
 
 
+def _cpu_one_shot(args):
+    """One shot (forward with saved wavefield + gradient) on one core; runs in a worker process."""
+    os.environ["OMP_NUM_THREADS"] = "1"
+    vp_true, vp_init, spacing, nbl, so, dt, src, rec, wavelet = args
+    from oracle import oracle as orc
+    p_true = orc.Problem(vp_true, spacing, nbl, so, dt=dt)
+    p_init = orc.Problem(vp_init, spacing, nbl, so, dt=dt)
+    obs = p_true.forward(src, wavelet, rec, dt=dt)[0]
+    t0 = time.perf_counter()
+    syn, u = p_init.forward(src, wavelet, rec, dt=dt, save=True)
+    p_init.gradient(rec, syn - obs, u, dt=dt)
+    return time.perf_counter() - t0
+
+
 def cpu_baseline(true_model, init_model, src, rec, wavelet, dt, space_order, nshots=2):
-    """Oracle (CPU restatement of the Devito path) on `nshots` shots of the same workload."""
+    """Oracle (CPU restatement of the Devito path) on a bounded sample of the same workload, two ways:
+    (i) as the reference runs it, shots one after the other, OpenMP over the grid of one shot (`value`);
+    (ii) best case for a CPU node, one shot per core side by side, one thread each (`shots_across_cores`)."""
     from oracle import oracle as orc
     nthreads = int(os.environ.get("OMP_NUM_THREADS", "0")) or (os.cpu_count() or 1)
     nbl = true_model.nbl
-    p_true = orc.Problem(true_model.vp.data[nbl:-nbl, nbl:-nbl], true_model.spacing, nbl, space_order, dt=dt)
-    p_init = orc.Problem(init_model.vp.data[nbl:-nbl, nbl:-nbl], true_model.spacing, nbl, space_order, dt=dt)
+    vt = np.ascontiguousarray(true_model.vp.data[nbl:-nbl, nbl:-nbl])
+    vi = np.ascontiguousarray(init_model.vp.data[nbl:-nbl, nbl:-nbl])
+    p_true = orc.Problem(vt, true_model.spacing, nbl, space_order, dt=dt)
+    p_init = orc.Problem(vi, true_model.spacing, nbl, space_order, dt=dt)
     obs = [p_true.forward(src[i], wavelet, rec, dt=dt)[0] for i in range(nshots)]
+    per_shot = 2 * (wavelet.shape[0] - 2) * int(np.prod(p_init.shape_pad))
     t0 = time.perf_counter()
     pts, reps = 0, 0
-    while reps < 1 or (time.perf_counter() - t0 < 10.0 and reps < 50):     # about 10 s of CPU work
+    while reps < 1 or (time.perf_counter() - t0 < 8.0 and reps < 50):     # about 8 s of CPU work
         for i in range(nshots):
             syn, u = p_init.forward(src[i], wavelet, rec, dt=dt, save=True)
             p_init.gradient(rec, syn - obs[i], u, dt=dt)
-            pts += 2 * (wavelet.shape[0] - 2) * int(np.prod(p_init.shape_pad))
+            pts += per_shot
         reps += 1
     el = time.perf_counter() - t0
-    return {"value": pts / el / 1e9, "unit": "Gpoints/s", "cores": nthreads, "kind": "port",
-            "sample": "%d shots of the same Marmousi-II workload (forward with saved wavefield + gradient, "
-                      "full nt=%d), %d passes, shots serial, OpenMP over the grid; %.1f s"
-                      % (nshots, wavelet.shape[0], reps, el)}
+    out = {"value": pts / el / 1e9, "unit": "Gpoints/s", "cores": nthreads, "kind": "port",
+           "omp_num_threads": nthreads, "binding": "none (threads placed by the OS scheduler)",
+           "mode": "shots serial, every core on one shot (OpenMP over the grid), as the reference's fwi.py:183-199 runs them",
+           "sample": "%d shots of the same Marmousi-II workload (forward with saved wavefield + gradient, "
+                     "full nt=%d), %d passes; %.1f s" % (nshots, wavelet.shape[0], reps, el)}
+    # (ii) one single-threaded shot per core, all at once
+    try:
+        import multiprocessing as mp
+        nproc = max(1, min(nthreads, 16))
+        args = [(vt, vi, tuple(true_model.spacing), nbl, space_order, dt, np.asarray(src[i % len(src)]), rec, wavelet)
+                for i in range(nproc)]
+        t0 = time.perf_counter()
+        with mp.get_context("spawn").Pool(nproc) as pool:
+            inner = pool.map(_cpu_one_shot, args)
+        wall = time.perf_counter() - t0
+        out["shots_across_cores"] = {
+            "value": nproc * per_shot / max(inner) / 1e9, "unit": "Gpoints/s", "cores": nproc, "omp_num_threads": 1,
+            "binding": "none (one process per shot, placed by the OS scheduler)",
+            "sample": "%d shots at once, one process and one thread each, full nt; slowest shot %.1f s "
+                      "(%.1f s with process start-up)" % (nproc, max(inner), wall)}
+    except Exception as e:      # the baseline is a report, never a reason to lose the bench line
+        out["shots_across_cores"] = {"error": repr(e)}
+    return out
 
 
 def roofline_3d(mifwi, device, space_order=16, n=512, nbl=40, nt=14):
@@ -238,15 +291,107 @@ def fwi_iteration(true_model, init_model, src_all, rec, k=3, reps=3):
     return (time.perf_counter() - t0) / reps * 1e3, k, float(f)
 
 
+class Survey(object):
+    """Device-resident state of one rank's share of a Marmousi-II survey: plan, observed data, mutes, outputs.
+    step() is one gradient evaluation of the L2 objective for these shots (+ all-reduce when distributed)."""
+
+    def __init__(self, mifwi, torch, dev, local_rank, true_model, init_model, src, rec, so, flags, dist=None):
+        from seismic import AcquisitionGeometry
+        from fwi import _mute_factor
+        self.torch, self.dist = torch, dist
+        self.ns = ns = src.shape[0]
+        geom = AcquisitionGeometry(true_model, rec, src[0], 0., 4500., f0=0.007, src_type='Ricker')
+        self.nt, self.dt = geom.nt, float(true_model.critical_dt)
+        self.wavelet = np.ascontiguousarray(geom.src.data)                       # (nt, 1) float32
+        self.shape_pad = true_model.grid.shape
+        self.ngrid = int(np.prod(self.shape_pad))
+        self.nbl = true_model.nbl
+        self.plan = mifwi.Plan(self.shape_pad, true_model.spacing, true_model.grid.origin, so, self.nt, self.dt, 1,
+                               rec.shape[0], max_shots=ns, dtype=np.float32, device=local_rank, flags=flags)
+        self.plan.set_geometry(src.reshape(ns, 1, 2), rec)
+        # everything the timed region reads is resident in HBM before it starts
+        d_vp_true = torch.from_numpy(np.ascontiguousarray(true_model.vp.data)).to(dev)
+        d_vp_init = torch.from_numpy(np.ascontiguousarray(init_model.vp.data)).to(dev)
+        d_damp = torch.from_numpy(np.ascontiguousarray(true_model.damp.data)).to(dev)
+        self.d_wavelet = torch.from_numpy(self.wavelet).to(dev)
+        self.d_obs = torch.empty((ns, self.nt, rec.shape[0]), dtype=torch.float32, device=dev)
+        self.plan.set_model(d_vp_true, d_damp)
+        self.plan.forward(self.d_wavelet, nshots=ns, rec_out=self.d_obs)        # observed data (untimed)
+        self.plan.set_model(d_vp_init, d_damp)
+        mute = np.stack([_mute_factor(true_model.shape, true_model.spacing, src[k], rec) for k in range(ns)])
+        self.d_mute = torch.from_numpy(mute.astype(np.float32)).to(dev)
+        self.d_grad = torch.zeros((ns,) + self.shape_pad, dtype=torch.float32, device=dev)
+        self.d_illum = torch.zeros_like(self.d_grad)
+        self.d_fval = torch.zeros(ns, dtype=torch.float64, device=dev)
+        torch.cuda.synchronize()
+
+    def step(self):
+        torch, nbl = self.torch, self.nbl
+        self.plan.l2_misfit_gradient(self.d_wavelet, self.d_obs, nshots=self.ns, grad=self.d_grad, illum=self.d_illum,
+                                     fval=self.d_fval, want_illum=True)
+        st = self.plan.stats()
+        g = (self.d_grad[:, nbl:-nbl, nbl:-nbl] * self.d_mute).sum(0)
+        il = (self.d_illum[:, nbl:-nbl, nbl:-nbl] * self.d_mute).sum(0)
+        packed = torch.cat([g.reshape(-1).double(), il.reshape(-1).double(), self.d_fval.sum().reshape(1)])
+        if self.dist is not None:
+            self.dist.all_reduce(packed)
+        return packed, st
+
+    def forward_only(self):
+        """Objective without gradient (a line-search trial): forward modelling + residual + norm."""
+        self.plan.l2_misfit_gradient(self.d_wavelet, self.d_obs, nshots=self.ns, calc_grad=False, fval=self.d_fval)
+        f = self.d_fval.sum().reshape(1)
+        if self.dist is not None:
+            self.dist.all_reduce(f)
+        return f
+
+    def close(self):
+        self.plan.close()
+
+
+def shot_batches(mifwi, torch, dev, local_rank, true_model, init_model, rec, so, flags, sizes=(4, 32), reps=3):
+    """The gradient evaluation of Survey.step for other batch sizes on this one GPU (shots spread over the line as in
+    a 32-shot survey).  BASELINE config 3 runs 32 shots on 8 GPUs, 4 each: time(32 shots) / time(4 shots) is the
+    speed-up that sharding can reach before the all-reduce (one message of 2 x 47 600 doubles + 1) is paid."""
+    out = {}
+    src32, _ = acquisition(true_model, 32)
+    for ns in sizes:
+        pick = src32[:: 32 // ns][:ns]
+        sv = Survey(mifwi, torch, dev, local_rank, true_model, init_model, pick, rec, so, flags)
+        sv.step()
+        torch.cuda.synchronize()
+        best = None
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            _, st = sv.step()
+            torch.cuda.synchronize()
+            ms = (time.perf_counter() - t0) * 1e3
+            if best is None or ms < best[0]:
+                best = (ms, st["fwd_ms"], st["bwd_ms"])
+        steps = sv.nt - 2
+        out["%d_shots" % ns] = {"gradient_eval_ms": best[0], "forward_us_per_step": best[1] / steps * 1e3,
+                                "gradient_us_per_step": best[2] / steps * 1e3,
+                                "gpoints_per_s": 2.0 * steps * sv.ngrid * ns / best[0] / 1e6}
+        sv.close()
+    if "4_shots" in out and "32_shots" in out:
+        out["speedup_32_shots_on_1_gpu_over_4_shots_per_gpu"] = (out["32_shots"]["gradient_eval_ms"] /
+                                                                 out["4_shots"]["gradient_eval_ms"])
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--space-order", type=int, default=16)
+    ap.add_argument("--shots-total", type=int, default=0,
+                    help="strong scaling: a fixed survey of this many shots split evenly over the GPUs (BASELINE config 3: "
+                         "32); default 0 = weak scaling, 8 shots per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-3d", action="store_true", help="skip the 3-D measurements (stencil roofline, 512^3 gradient)")
     ap.add_argument("--no-tti", action="store_true", help="skip the 2-D TTI measurement")
+    ap.add_argument("--no-batches", action="store_true", help="skip the 4- and 32-shot batch timings")
     ap.add_argument("--flags", type=int, default=0, help="MIFWI_FLAG_* bits for the plan (debugging)")
     args = ap.parse_args()
 
@@ -276,53 +421,19 @@ def main():
 
     so = args.space_order
     true_model, init_model = marmousi2(so)
-    nshots_total = SHOTS_PER_GPU * world
+    strong = args.shots_total > 0
+    if strong and args.shots_total % world:
+        raise SystemExit("--shots-total %d is not a multiple of %d GPUs" % (args.shots_total, world))
+    per_gpu = args.shots_total // world if strong else SHOTS_PER_GPU
+    nshots_total = per_gpu * world
     src_all, rec = acquisition(true_model, nshots_total)
-    mine = list(range(rank * SHOTS_PER_GPU, (rank + 1) * SHOTS_PER_GPU))
-    src = src_all[mine]
+    src = src_all[rank * per_gpu:(rank + 1) * per_gpu]
 
-    from seismic import AcquisitionGeometry
-    geom = AcquisitionGeometry(true_model, rec, src[0], 0., 4500., f0=0.007, src_type='Ricker')
-    nt, dt = geom.nt, float(true_model.critical_dt)
-    wavelet = np.ascontiguousarray(geom.src.data)                       # (nt, 1) float32
-    shape_pad = true_model.grid.shape
-    ngrid = int(np.prod(shape_pad))
-    nbl = true_model.nbl
-
-    plan = mifwi.Plan(shape_pad, true_model.spacing, true_model.grid.origin, so, nt, dt, 1, rec.shape[0],
-                      max_shots=SHOTS_PER_GPU, dtype=np.float32, device=local_rank, flags=args.flags)
-    plan.set_geometry(src.reshape(SHOTS_PER_GPU, 1, 2), rec)
-
-    # everything the timed region reads is resident in HBM before it starts
-    d_vp_true = torch.from_numpy(np.ascontiguousarray(true_model.vp.data)).to(dev)
-    d_vp_init = torch.from_numpy(np.ascontiguousarray(init_model.vp.data)).to(dev)
-    d_damp = torch.from_numpy(np.ascontiguousarray(true_model.damp.data)).to(dev)
-    d_wavelet = torch.from_numpy(wavelet).to(dev)
-    d_obs = torch.empty((SHOTS_PER_GPU, nt, rec.shape[0]), dtype=torch.float32, device=dev)
-    plan.set_model(d_vp_true, d_damp)
-    plan.forward(d_wavelet, nshots=SHOTS_PER_GPU, rec_out=d_obs)        # observed data (untimed)
-    plan.set_model(d_vp_init, d_damp)
-
-    from fwi import _mute_factor
-    mute = np.stack([_mute_factor(true_model.shape, true_model.spacing, src[k], rec) for k in range(SHOTS_PER_GPU)])
-    d_mute = torch.from_numpy(mute.astype(np.float32)).to(dev)
-    d_grad = torch.zeros((SHOTS_PER_GPU,) + shape_pad, dtype=torch.float32, device=dev)
-    d_illum = torch.zeros_like(d_grad)
-    d_fval = torch.zeros(SHOTS_PER_GPU, dtype=torch.float64, device=dev)
-    torch.cuda.synchronize()
+    coll = dist if use_dist else None
+    sv = Survey(mifwi, torch, dev, local_rank, true_model, init_model, src, rec, so, args.flags, coll)
+    nt, ngrid, shape_pad = sv.nt, sv.ngrid, sv.shape_pad
 
     fwd_stats, grad_stats = [], []
-
-    def step():
-        plan.l2_misfit_gradient(d_wavelet, d_obs, nshots=SHOTS_PER_GPU, grad=d_grad, illum=d_illum, fval=d_fval,
-                                want_illum=True)
-        st = plan.stats()
-        g = (d_grad[:, nbl:-nbl, nbl:-nbl] * d_mute).sum(0)
-        il = (d_illum[:, nbl:-nbl, nbl:-nbl] * d_mute).sum(0)
-        packed = torch.cat([g.reshape(-1).double(), il.reshape(-1).double(), d_fval.sum().reshape(1)])
-        if use_dist:
-            dist.all_reduce(packed)
-        return packed, st
 
     def barrier():
         torch.cuda.synchronize()
@@ -334,11 +445,11 @@ def main():
         # communicator set-up is lazy (first collective); keep it out of the timed region even with --warmup 0
         dist.all_reduce(torch.zeros(1, dtype=torch.float64, device=dev))
     for _ in range(args.warmup):
-        step()
+        sv.step()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        packed, st = step()
+        packed, st = sv.step()
         fwd_stats.append((st["fwd_ms"], st["fwd_launches"]))
         grad_stats.append((st["bwd_ms"], st["bwd_launches"]))
         if os.environ.get("BENCH_VERBOSE"):
@@ -350,7 +461,16 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    pts_per_step = 2.0 * (nt - 2) * ngrid * SHOTS_PER_GPU * world
+    # forward-only objective evaluations (line-search trials), same protocol
+    sv.forward_only()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        sv.forward_only()
+    barrier()
+    fwd_only_ms = (time.perf_counter() - t0) / args.steps * 1e3
+
+    pts_per_step = 2.0 * (nt - 2) * ngrid * per_gpu * world
     value = pts_per_step * args.steps / elapsed / 1e9
     fval = float(packed[-1].item())
 
@@ -362,10 +482,11 @@ def main():
     fwd_ms = float(np.mean([m for m, _ in fwd_stats]))
     fwd_launches = fwd_stats[-1][1]
     steps_per_loop = nt - 2
-    g_bytes_loop = 32.0 * ngrid * SHOTS_PER_GPU * steps_per_loop
-    f_bytes_loop = 20.0 * ngrid * SHOTS_PER_GPU * steps_per_loop
+    g_bytes_loop = 32.0 * ngrid * per_gpu * steps_per_loop
+    f_bytes_loop = 20.0 * ngrid * per_gpu * steps_per_loop
     g_ach = g_bytes_loop / (bwd_ms * 1e-3) / 1e9
     f_ach = f_bytes_loop / (fwd_ms * 1e-3) / 1e9
+    prof_us = profile_launch_us(st["bwd_kernel"])
     roofline = {"bound": "hbm", "achieved": g_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": g_ach / HBM_PEAK_GBS, "traffic": pmc_traffic(st["bwd_kernel"]),
                 "kernel": st["bwd_kernel"], "launches_per_loop": bwd_launches,
@@ -373,30 +494,39 @@ def main():
                 "bytes_per_launch": g_bytes_loop / max(1, bwd_launches),
                 "timing": "HIP events around the backward time loop on the plan's stream / launches "
                           "(includes inter-kernel gaps)",
+                "profile_avg_launch_us": prof_us,
+                "profile_frac": (g_bytes_loop / max(1, bwd_launches)) / (prof_us * 1e-6) / 1e9 / HBM_PEAK_GBS
+                if prof_us else None,
+                "profile": "profiles/r2_bench_kernel_stats.txt: rocprofv3 --kernel-trace of this command, mean over "
+                           "the backward loop's launches (plain and two-step gradient launches weighted by count)",
                 "schedule": "the loop alternates a plain step (step2d_kernel mode 0) and a step that adds the "
                             "gradient terms of both (mode 4); launch time, bytes and traffic are means over the loop"}
     roofline_fwd = {"bound": "hbm", "achieved": f_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": f_ach / HBM_PEAK_GBS, "traffic": pmc_traffic(st["fwd_kernel"]), "kernel": st["fwd_kernel"],
-                    "launches_per_loop": fwd_launches, "avg_launch_us": fwd_ms * 1e3 / max(1, fwd_launches)}
+                    "launches_per_loop": fwd_launches, "avg_launch_us": fwd_ms * 1e3 / max(1, fwd_launches),
+                    "profile_avg_launch_us": profile_launch_us(st["fwd_kernel"])}
 
     out = {
-        "metric": "Gpoints/s (fwd+adj), Marmousi-II, 8 shots per GPU",
+        "metric": "Gpoints/s (fwd+adj), Marmousi-II, %s" % ("%d-shot survey sharded over the GPUs" % nshots_total if strong
+                                                           else "8 shots per GPU"),
         "value": value, "unit": "Gpoints/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong" if strong else "weak",
         "vs_baseline": None, "dtype": "f32",
         "data": "Marmousi-II vp rasters of the reference (model_data/SMARM2); observed data synthesised by "
                 "forward modelling the true model; start model = smooth_20",
         "config": {"workload": "Marmousi-II (SMARM2 340x140, nbl 40 -> 420x220) acoustic, space_order=%d, "
-                               "dt=3.0 ms, nt=%d, %d shots per GPU, L2 misfit gradient (forward with saved "
+                               "dt=3.0 ms, nt=%d, %d shots per GPU%s, L2 misfit gradient (forward with saved "
                                "wavefield + adjoint/gradient + per-shot muting + shot sum%s)"
-                               % (so, nt, SHOTS_PER_GPU, " + RCCL all-reduce" if world > 1 else ""),
+                               % (so, nt, per_gpu, " (BASELINE config 3: %d shots in all)" % nshots_total if strong else "",
+                                  " + RCCL all-reduce" if world > 1 else ""),
                    "shots_total": nshots_total, "grid_padded": list(shape_pad), "nt": nt, "space_order": so,
-                   "parallelism": "shots sharded %d per GPU" % SHOTS_PER_GPU},
+                   "parallelism": "shots sharded %d per GPU" % per_gpu},
         "gradient_eval_ms": elapsed / args.steps * 1e3,
+        "forward_only_eval_ms": fwd_only_ms,
         "objective": fval,
         "roofline": roofline, "roofline_forward": roofline_fwd,
     }
-    plan.close()
+    sv.close()
     it_ms, it_k, it_f = fwi_iteration(true_model, init_model, src_all, rec)
     if use_dist:
         t = torch.tensor([it_ms], dtype=torch.float64, device=dev)
@@ -404,10 +534,13 @@ def main():
         it_ms = float(t.item())
     out["fwi_iteration"] = {"ms": it_ms, "gradient_evaluations": 1, "forward_only_evaluations": it_k,
                             "shots": nshots_total, "objective": it_f,
+                            "expected_from_parts_ms": out["gradient_eval_ms"] + it_k * fwd_only_ms,
                             "what": "fwi.fwi_loss through the Python API: model update, batched shots, "
                                     "muting, preconditioner, mask, all-reduce"}
+    if rank == 0 and world == 1 and not args.no_batches and not strong:
+        out["shot_batches"] = shot_batches(mifwi, torch, dev, local_rank, true_model, init_model, rec, so, args.flags)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(true_model, init_model, src_all, rec, wavelet, dt, so)
+        out["cpu_baseline"] = cpu_baseline(true_model, init_model, src_all, rec, sv.wavelet, sv.dt, so)
     if rank == 0 and world == 1 and not args.no_3d:
         # the north-star stencil: 16th-order 3-D forward step against the HBM roofline
         out["roofline_3d"] = roofline_3d(mifwi, local_rank, space_order=16)

@@ -140,6 +140,39 @@ def shot_partition(nshots, rank=None, world=None):
     return list(range(start, start + base + (1 if rank < extra else 0)))
 
 
+_MUTE_DEV = {}
+
+
+def _mute_factors_device(model, geometry, shots, device):
+    """(ns, nx, nz) float64 tensor of the shots' mute factors on `device`, kept for the survey."""
+    import torch
+    key = (tuple(model.shape), tuple(float(s) for s in model.spacing), geometry.src_positions[shots].tobytes(),
+           geometry.rec_positions.tobytes(), str(device))
+    t = _MUTE_DEV.get(key)
+    if t is None:
+        m = np.stack([_mute_factor(model.shape, model.spacing, geometry.src_positions[i], geometry.rec_positions)
+                      for i in shots])
+        t = torch.from_numpy(np.ascontiguousarray(m, dtype=np.float64)).to(device)
+        if len(_MUTE_DEV) > 16:
+            _MUTE_DEV.clear()
+        _MUTE_DEV[key] = t
+    return t
+
+
+def _all_reduce_sum_device(packed):
+    """Sum a float64 tensor over the ranks where it lives: RCCL for a GPU tensor under the nccl backend;
+    under gloo (CPU rehearsals) it travels through the host."""
+    dist = _dist()
+    if dist is None or dist.get_world_size() == 1:
+        return packed
+    if dist.get_backend() == 'nccl' or not packed.is_cuda:
+        dist.all_reduce(packed, op=dist.ReduceOp.SUM)
+        return packed
+    host = packed.cpu()
+    dist.all_reduce(host, op=dist.ReduceOp.SUM)
+    return host.to(packed.device)
+
+
 def _all_reduce_sum(fval, arrays):
     """Sum a scalar and a list of float64 numpy arrays over the ranks (RCCL when the arrays'
     home is a GPU process group, gloo on CPU)."""
@@ -289,6 +322,14 @@ class _ResidualList(object):
         return (self[i] for i in range(len(self)))
 
 
+def _grid_outputs(plan, ns, dtype):
+    """Device tensors for the per-shot padded-grid gradients and illuminations of a batch: they are cropped,
+    muted and summed where they are, and only the summed physical-grid arrays ever cross to the host."""
+    import torch
+    shape = (ns,) + tuple(plan.shape)
+    return torch.empty(shape, dtype=dtype, device='cuda'), torch.empty(shape, dtype=dtype, device='cuda')
+
+
 def _compute_batch(geometry, shots, obs, direct_wave, misfit_func, calc_grad):
     """Objective pieces of the shots `shots` (indices into the survey) as one GPU batch:
     (fvals per shot, residuals (ns, nt, nrec), padded-grid gradients (ns, *grid) or None,
@@ -304,8 +345,9 @@ def _compute_batch(geometry, shots, obs, direct_wave, misfit_func, calc_grad):
         import torch
         obs_dev = _resident_batch(plan, obs, shots, model.dtype)
         res_dev = torch.empty_like(obs_dev)
+        g_dev, il_dev = _grid_outputs(plan, ns, obs_dev.dtype) if calc_grad else (None, None)
         out = plan.l2_misfit_gradient(wavelet, obs_dev, nshots=ns, calc_grad=calc_grad, want_illum=True,
-                                      residual=res_dev)
+                                      residual=res_dev, grad=g_dev, illum=il_dev)
         return out['fval'], _DeviceResiduals(res_dev), out['grad'], out['illum']
     if DEVICE_MISFIT and getattr(misfit_func, 'method', None) == '1d' and hasattr(misfit_func, 'batch_device'):
         # trace-wise misfits with a batched tensor form: the gathers stay on the device between the passes
@@ -320,7 +362,8 @@ def _compute_batch(geometry, shots, obs, direct_wave, misfit_func, calc_grad):
         fvals, res_dev = misfit_func.batch_device(f_dev, o_dev)
         g_b = il_b = None
         if calc_grad:
-            g_b, il_b = plan.gradient(res_dev, nshots=ns, want_illum=True)
+            g_b, il_b = _grid_outputs(plan, ns, obs_dev.dtype)
+            plan.gradient(res_dev, nshots=ns, grad=g_b, illum=il_b)
         return fvals.cpu().numpy(), _DeviceResiduals(res_dev), g_b, il_b
     obs_b = np.stack([obs[i].data for i in shots]).astype(model.dtype, copy=False)
     dw_b = None
@@ -338,7 +381,9 @@ def _compute_batch(geometry, shots, obs, direct_wave, misfit_func, calc_grad):
         res_b[k] = r_
     g_b = il_b = None
     if calc_grad:
-        g_b, il_b = plan.gradient(res_b, nshots=ns, want_illum=True)
+        import torch
+        g_b, il_b = _grid_outputs(plan, ns, torch.float32 if model.dtype == np.float32 else torch.float64)
+        plan.gradient(res_b, nshots=ns, grad=g_b, illum=il_b)
     return fvals, res_b, g_b, il_b
 
 
@@ -473,10 +518,30 @@ def fwi_obj_multi(geometry, obs, misfit_func, direct_wave=None, mask=None, preco
         for k, i in enumerate(mine):
             fval += float(fvals[k])
             residuals._set(i, res_b, k)
-            if calc_grad:
+        if calc_grad and type(g_b).__module__.startswith('torch'):
+            # device route: crop, mute (per shot, before the sum, as fwi.py:166-171 of the reference does), shot sum,
+            # all-reduce, preconditioner and mask on the GPU, in float64 like the host route; one small copy back
+            import torch
+            sl = (slice(None),) + tuple(crop)
+            mutes = _mute_factors_device(model, geometry, mine, g_b.device)
+            g_sum = (g_b[sl].double() * mutes).sum(0)
+            il_sum = (il_b[sl].double() * mutes).sum(0)
+            packed = torch.cat([torch.tensor([fval], dtype=torch.float64, device=g_b.device), g_sum.reshape(-1),
+                                il_sum.reshape(-1)])
+            packed = _all_reduce_sum_device(packed)
+            n = g_sum.numel()
+            g_sum, il_sum = packed[1:1 + n].reshape(g_sum.shape), packed[1 + n:].reshape(g_sum.shape)
+            if precond:
+                g_sum = g_sum / torch.sqrt(il_sum + 1e-30)
+            if mask is not None:
+                g_sum = g_sum * torch.as_tensor(np.ascontiguousarray(mask, dtype=np.float64), device=g_sum.device)
+            host = torch.cat([packed[:1], g_sum.reshape(-1)]).cpu().numpy()
+            return float(host[0]), host[1:].copy(), residuals
+        if calc_grad:
+            for k, i in enumerate(mine):
                 mute = _mute_factor(model.shape, model.spacing, geometry.src_positions[i], geometry.rec_positions)
-                grad += g_b[k][crop] * mute
-                illum += il_b[k][crop] * mute
+                grad += np.asarray(g_b[k])[crop] * mute
+                illum += np.asarray(il_b[k])[crop] * mute
     if calc_grad:
         fval, (grad, illum) = _all_reduce_sum(fval, [grad, illum])
         if precond:
