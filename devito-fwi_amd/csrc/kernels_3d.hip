@@ -57,12 +57,8 @@ __device__ inline void ldv(const char *base, unsigned off, float (&d)[V])
 template <int V>
 __device__ inline void ldv_stream(const char *base, unsigned off, float (&d)[V])
 {
-#ifdef MIFWI_3D_PLAIN_LOAD
-    const typename VecT<V>::type v = *reinterpret_cast<const typename VecT<V>::type *>(base + off);
-#else
     const typename VecT<V>::type v =
         __builtin_nontemporal_load(reinterpret_cast<const typename VecT<V>::type *>(base + off));
-#endif
 #pragma unroll
     for (int i = 0; i < V; ++i) d[i] = v[i];
 }
@@ -72,11 +68,7 @@ __device__ inline void stv_stream(char *base, unsigned off, const float (&d)[V])
     typename VecT<V>::type v;
 #pragma unroll
     for (int i = 0; i < V; ++i) v[i] = d[i];
-#ifdef MIFWI_3D_PLAIN_STORE
-    *reinterpret_cast<typename VecT<V>::type *>(base + off) = v;
-#else
     __builtin_nontemporal_store(v, reinterpret_cast<typename VecT<V>::type *>(base + off));
-#endif
 }
 // V consecutive points of a half-precision saved level; `off` is their byte offset in a float field
 typedef unsigned vu2 __attribute__((ext_vector_type(2)));
@@ -342,11 +334,7 @@ __global__ __launch_bounds__(TY *TZ / V, (MODE == 1 || MODE == 2 || MODE == 4 ? 
         if (x + 1 < xb) {
 #pragma unroll
             for (int i = 0; i < NHT; ++i)
-#ifdef MIFWI_3D_RING_NT
-                if (h_ok[i]) ldv_stream<4>(cur + (long)(x + 1) * sb, h_glb[i], hv[i]);
-#else
                 if (h_ok[i]) ldv<4>(cur + (long)(x + 1) * sb, h_glb[i], hv[i]);
-#endif
             if (PF) {
 #pragma unroll
                 for (int i = 0; i < V; ++i) ee_n[i] = 0.f;

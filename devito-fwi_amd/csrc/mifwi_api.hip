@@ -506,7 +506,7 @@ static int create(const mifwi_config *cfg, mifwi_plan **out)
         p->kind = 2;
         if (const char *env = getenv("MIFWI_3D_VEC")) p->vec3d = atoi(env);  // tuning experiments
         p->tile_tx = 16, p->tile_tz = 64;
-        p->ntx = (p->L.n[1] + 15) / 16;
+        p->ntx = (p->L.n[1] + p->tile_tx - 1) / p->tile_tx;
         p->ntz = (p->L.n[2] + 63) / 64;
         hipDeviceProp_t prop{};
         if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) p->ncu = prop.multiProcessorCount;

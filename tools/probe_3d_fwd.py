@@ -6,8 +6,9 @@ sys.path[:0] = [ROOT, os.path.join(ROOT, "devito-fwi_amd")]
 import mifwi
 from seismic import Model
 n, so, nt = 512, (int(sys.argv[1]) if len(sys.argv) > 1 else 16), 14
-vp = np.empty((n, n, n), dtype=np.float32)
-vp[:] = np.linspace(1.5, 4.5, n, dtype=np.float32)[None, None, :]
+nz = int(sys.argv[2]) if len(sys.argv) > 2 else n      # physical z extent (x and y stay at 512)
+vp = np.empty((n, n, nz), dtype=np.float32)
+vp[:] = np.linspace(1.5, 4.5, nz, dtype=np.float32)[None, None, :]
 model = Model(origin=(0., 0., 0.), spacing=(10., 10., 10.), shape=vp.shape, space_order=so, vp=vp, nbl=40, bcs="damp")
 dt = float(model.critical_dt)
 sp = model.grid.shape
@@ -28,6 +29,6 @@ for _ in range(4):
     st = plan.stats()
     best = min(best, st["fwd_ms"] / st["fwd_launches"])
 u = plan.read_wavefield(1, shot=0)
-print("so=%d tile=%s chunks=%s: %.4f ms/step  %.1f Gpts/s  %.1f%% of 8 TB/s   |rec| %.8e |u| %.8e" %
+print("nz=%d " % sp[2] + "so=%d tile=%s chunks=%s: %.4f ms/step  %.1f Gpts/s  %.1f%% of 8 TB/s   |rec| %.8e |u| %.8e" %
       (so, os.environ.get("MIFWI_3D_TILE", "16x64"), os.environ.get("MIFWI_3D_NCHUNK", "auto"), best, ngrid / best / 1e6,
        20 * ngrid / best / 1e6 / 80, float(np.linalg.norm(d.astype(np.float64))), float(np.linalg.norm(u.astype(np.float64)))), flush=True)
