@@ -171,6 +171,8 @@ static void destroy(Plan *p)
     dev_free(p->tti_adj);
     dev_free(p->tti_tmp);
     dev_free(p->tti_save);
+    dev_free(p->tti_ckpt);
+    dev_free(p->tti_seg);
     dev_free(p->d_save_scale);
     dev_free(p->d_t4);
     dev_free(p->d_w2);
@@ -576,6 +578,7 @@ static int set_model(Plan &p, const void *vp, const void *damp)
         p.saved_valid = false;
         p.ck_model_changed = true;
     }
+    if (p.tti_ck_K > 0) p.tti_save_valid = false;
     if (p.kind == 2) {
         if (!p.eta_zero && (rc = dev_alloc(p, (void **)&p.eta_zero, (size_t)p.ntx * p.ntz * p.L.n[0], true))) return rc;
         if ((rc = launch_eta_zero(p, p.eta_zero))) return rc;
@@ -632,6 +635,8 @@ static void fill_stats(Plan &p, double ms, double steps, int nshots, double byte
     p.stats.launches = launches;
     p.stats.kernel_kind = p.kind;
     p.stats.device_bytes = p.device_bytes;
+    p.stats.ckpt_steps = p.ck_K > 0 ? p.ck_nc : 0;
+    p.stats.ckpt_segment = p.ck_K;
     // MIFWI_FLAG_ASYNC: the loop has only been enqueued and ms is unknown; resolve_stats() fills the times in
     p.timing_pending[backward ? 1 : 0] = (p.cfg.flags & MIFWI_FLAG_ASYNC) != 0;
     p.timing_last = backward ? 1 : 0;
@@ -1089,10 +1094,11 @@ static int copy_levels(Plan &p, T *dst, long dst_stride, const T *src, long src_
 }
 
 // Decide, on the first saving forward run, how the forward wavefield is kept for the gradient:
-// every level (ck_K = 0) when that fits in free device memory, else two-level checkpointing:
-// the levels entering every ck_K-th step are kept and each segment is recomputed into a segment
-// buffer right before the backward pass crosses it.  The gradient is bit-identical either way
-// (same kernels, same order); the price is one more forward sweep.
+// every level (ck_K = 0) when that fits in free device memory, else two-level checkpointing of as
+// few of the first steps as memory demands: the levels entering every ck_K-th step are kept and each
+// segment is recomputed into a segment buffer right before the backward pass crosses it, while the
+// levels of the remaining steps are stored one by one.  The gradient is bit-identical in every case
+// (same kernels, same order); the price is a second propagation of the checkpointed steps.
 template <typename T>
 static int prepare_save(Plan &p)
 {
@@ -1101,6 +1107,8 @@ static int prepare_save(Plan &p)
     const size_t level = (size_t)p.cfg.max_shots * p.L.field * sizeof(T);
     size_t free_b = 0, total_b = 0;
     MIFWI_HIP(hipMemGetInfo(&free_b, &total_b));
+    if (const char *env = getenv("MIFWI_SAVE_BUDGET_MB"))   // tests: pretend that less memory is free
+        free_b = std::min(free_b, (size_t)std::max(1L, atol(env)) << 20);
     const bool force = (p.cfg.flags & MIFWI_FLAG_CHECKPOINT) != 0;
     // half-precision levels: float32 plans on the tiled kernels only
     const bool want_f16 = (p.cfg.flags & MIFWI_FLAG_SAVE_F16) && std::is_same<T, float>::value && p.kind != 0;
@@ -1116,18 +1124,41 @@ static int prepare_save(Plan &p)
     }
     p.save_f16 = false;   // checkpoints restart the propagation and stay float32
     const int nsteps = nt - 2;
-    p.ck_K = std::max(2, (int)std::ceil(std::sqrt(2.0 * nsteps)));
-    p.ck_K += p.ck_K & 1;   // even: segments then start at odd times and never split a pair of gradient steps
-    p.ck_nseg = (nsteps + p.ck_K - 1) / p.ck_K;
-    const size_t need = level * (2 * (size_t)p.ck_nseg + p.ck_K + 2);
-    if ((double)need > 0.95 * (double)free_b)
+    // Checkpoint the first ck_nc steps (segments of ck_K steps, ck_K even so that segments start at odd times and
+    // never split a pair of gradient steps) and store every level from ck_nc on.  Memory in levels:
+    // (nt - nc) stored + 2 per segment + ck_K + 2 for the segment being recomputed.  Of all (nc, K) that fit,
+    // the smallest nc wins: only those steps are propagated a second time.  The tiled 2-D kernel and a forced
+    // MIFWI_FLAG_CHECKPOINT checkpoint everything.
+    const double budget = 0.90 * (double)free_b / (double)level;
+    const bool all = force || p.kind == 1;
+    int best_nc = -1, best_K = 0;
+    for (int K = 2; !all && K <= nsteps; K += 2) {
+        for (int nseg = 1; nseg * K < nsteps; ++nseg) {
+            const int nc = nseg * K;
+            if ((double)(nt - nc) + 2.0 * nseg + K + 2 > budget) continue;
+            if (best_nc < 0 || nc < best_nc) best_nc = nc, best_K = K;
+            break;   // more segments of this K only recompute more
+        }
+    }
+    if (best_nc < 0) {   // everything checkpointed: K ~ sqrt(2 nsteps) minimises the memory
+        int K = std::max(2, (int)std::ceil(std::sqrt(2.0 * nsteps)));
+        K += K & 1;
+        const int nseg = (nsteps + K - 1) / K;
+        if (2.0 * nseg + K + 2 <= 0.95 * (double)free_b / (double)level) best_nc = nsteps, best_K = K;
+    }
+    if (best_nc < 0)
         return fail(MIFWI_ENOMEM, "not enough device memory even for the checkpointed wavefield (" +
-                                      std::to_string(need >> 20) + " MiB needed)");
+                                      std::to_string((size_t)free_b >> 20) + " MiB free)");
+    p.ck_K = best_K;
+    p.ck_nc = best_nc;
+    p.ck_nseg = (best_nc + best_K - 1) / best_K;
     if ((rc = dev_alloc(p, &p.ckpt, level * 2 * p.ck_nseg, true))) return rc;
     // the recomputation must see the wavelet of the run that took the checkpoints, whatever is modelled between
     if ((rc = dev_alloc(p, &p.d_wavelet_ck, (size_t)p.cfg.max_shots * nt * std::max(1, p.cfg.nsrc) * sizeof(T), true)))
         return rc;
-    return dev_alloc(p, &p.seg, level * (p.ck_K + 2), true);
+    if ((rc = dev_alloc(p, &p.seg, level * (p.ck_K + 2), true))) return rc;
+    if (p.ck_nc < nsteps) return dev_alloc(p, &p.saved, level * (size_t)(nt - p.ck_nc), true);   // levels ck_nc .. nt-1
+    return MIFWI_OK;
 }
 
 // forward time loop on data already resident on the device (d_wavelet -> d_rec)
@@ -1175,6 +1206,9 @@ static int run_forward(Plan &p, int nshots, int save)
     const bool in_saved = full_save && !copy_save;
     auto lvl = [&](int t) { return in_saved ? base + (long)t * sv_lstride : base + (long)(t % 3) * L.field; };
     const bool ckpt = save && !full_save;
+    // steps after ck_nc of a checkpointed plan run inside the stored levels (`saved` holds levels ck_nc .. nt-1)
+    const bool mixed = ckpt && p.ck_nc < nt - 2;
+    auto stored = [&](int t) { return (T *)p.saved + (long)(t - p.ck_nc) * sv_lstride; };
     // Two steps per sweep over the grid (2.5-D kernel, nothing saved): x is cut into slabs of slab_w planes and
     // the second step follows the first one slab behind, so that what it reads -- the level the first step has
     // just written, the level before it and the coefficients -- is still in the 256 MB last-level cache.
@@ -1213,7 +1247,7 @@ static int run_forward(Plan &p, int nshots, int save)
     auto enqueue = [&](int &launches) -> int {
         if (slab_w > 0) return enqueue_slabs(launches);
         for (int time = 1; time <= nt - 2; ++time) {
-            if (ckpt && (time - 1) % p.ck_K == 0) {
+            if (ckpt && time <= p.ck_nc && (time - 1) % p.ck_K == 0) {
                 // keep the two levels that enter this segment: u[time-1], u[time]
                 const int j = (time - 1) / p.ck_K;
                 T *dst = (T *)p.ckpt + (long)j * 2 * L.field;
@@ -1221,6 +1255,17 @@ static int run_forward(Plan &p, int nshots, int save)
                 int r;
                 if ((r = copy_levels<T>(p, dst, cstride, lvl(time - 1), shot_stride, 1, nshots))) return r;
                 if ((r = copy_levels<T>(p, dst + L.field, cstride, lvl(time), shot_stride, 1, nshots))) return r;
+            }
+            if (mixed && time > p.ck_nc) {
+                int r;
+                if (time == p.ck_nc + 1) {   // hand the two levels entering the stored part over to it
+                    if ((r = copy_levels<T>(p, stored(time - 1), L.field, lvl(time - 1), shot_stride, 1, nshots))) return r;
+                    if ((r = copy_levels<T>(p, stored(time), L.field, lvl(time), shot_stride, 1, nshots))) return r;
+                }
+                if ((r = forward_step<T>(p, ctx, stored(time), stored(time - 1), stored(time + 1), L.field, time, true,
+                                         launches)))
+                    return r;
+                continue;
             }
             auto saved_at = [&](int level) { return (T *)((char *)p.saved + (size_t)level * sv_lstride * es); };
             T *copy = copy_save ? saved_at(time + 1) : nullptr, *copy_prev = nullptr;
@@ -1245,7 +1290,7 @@ static int run_forward(Plan &p, int nshots, int save)
         p.saved_valid = true;
         p.saved_shots = nshots;
     }
-    if (!in_saved) p.rot_u_valid = true;
+    if (!in_saved && !mixed) p.rot_u_valid = true;
     return MIFWI_OK;
 }
 
@@ -1321,12 +1366,25 @@ static int run_backward(Plan &p, int nshots, bool with_grad, bool with_illum)
             }
             return MIFWI_OK;
         }
-        // checkpointed: walk the segments backwards, recomputing each into the segment buffer first
+        // checkpointed.  The steps after ck_nc come first: their levels are stored (`saved` holds ck_nc .. nt-1)
+        {
+            const long sv_lstride = (long)p.cfg.max_shots * L.field;
+            auto stored = [&](int t) { return (const T *)p.saved + (long)(t - p.ck_nc) * sv_lstride; };
+            for (int time = nt - 2; time > p.ck_nc; --time) {
+                const int role = pair_role(time);
+                const bool u = role != 1;
+                if ((r = backward_step<T>(p, role == 1 ? fctx : ctx, lvl(time), lvl(time + 1), lvl(time - 1), shot_stride, time,
+                                          u ? stored(time - 1) : nullptr, u ? stored(time) : nullptr,
+                                          u ? stored(time + 1) : nullptr, L.field, with_illum, time == nt - 2, launches, role)))
+                    return r;
+            }
+        }
+        // then walk the segments backwards, recomputing each into the segment buffer first
         T *seg = (T *)p.seg;
         const long seg_stride = (long)(p.ck_K + 2) * L.field;
         const long cstride = (long)p.ck_nseg * 2 * L.field;
         for (int j = p.ck_nseg - 1; j >= 0; --j) {
-            const int t0 = 1 + j * p.ck_K, t1 = std::min(nt - 2, t0 + p.ck_K - 1);
+            const int t0 = 1 + j * p.ck_K, t1 = std::min(p.ck_nc, t0 + p.ck_K - 1);
             // seg level i holds u[t0 - 1 + i]
             if ((r = copy_levels<T>(p, seg, seg_stride, (const T *)p.ckpt + (long)j * 2 * L.field, cstride, 2, nshots)))
                 return r;
@@ -1582,6 +1640,7 @@ static int tti_set_model(Plan &p, const void *eps, const void *delta, const void
         }
         if ((rc = launch_tti_param<T>(p, k, src, par + (long)f * p.L.field, spec[f].mode, spec[f].halo))) return rc;
     }
+    if (p.tti_ck_K > 0) p.tti_save_valid = false;   // checkpoints belong to the parameters they were taken with
     return finish(p);   // wavefields of earlier runs stay readable: they are not touched here
 }
 
@@ -1694,21 +1753,47 @@ static int tti_run(Plan &p, int nshots, int mode, int save)
     const Layout &L = p.L;
     const int nt = p.cfg.nt;
     const long S = p.cfg.max_shots;
-    if (save && !p.tti_save) {
+    if (save && !p.tti_save && !p.tti_ckpt) {
+        // every level of both fields when that fits, else two-level checkpointing as for the acoustic wavefield
+        // (prepare_save): two levels of u and v entering every tti_ck_K-th step, segments recomputed by the gradient
         const size_t need = (size_t)2 * S * nt * L.field * sizeof(T);
         size_t free_b = 0, total_b = 0;
         MIFWI_HIP(hipMemGetInfo(&free_b, &total_b));
-        if ((double)need > 0.9 * (double)free_b)
-            return fail(MIFWI_ENOMEM, "saving both TTI fields needs " + std::to_string(need >> 20) +
-                                          " MiB of device memory (no checkpointing on this path): use fewer shots per call");
+        if (const char *env = getenv("MIFWI_SAVE_BUDGET_MB"))   // tests: pretend that less memory is free
+            free_b = std::min(free_b, (size_t)std::max(1L, atol(env)) << 20);
         clear_graphs(p);
-        if ((rc = dev_alloc(p, &p.tti_save, need, true))) return rc;
+        if (!(p.cfg.flags & MIFWI_FLAG_CHECKPOINT) && (double)need <= 0.9 * (double)free_b) {
+            if ((rc = dev_alloc(p, &p.tti_save, need, true))) return rc;
+        } else {
+            const int nsteps = nt - 2;
+            int K = std::max(2, (int)std::ceil(std::sqrt(2.0 * nsteps)));
+            K += K & 1;
+            const int nseg = (nsteps + K - 1) / K;
+            const size_t fb = (size_t)S * L.field * sizeof(T);
+            const size_t need_ck = 2 * fb * (2 * (size_t)nseg + K + 2);
+            if ((double)need_ck > 0.95 * (double)free_b)
+                return fail(MIFWI_ENOMEM, "not enough device memory even for the checkpointed TTI wavefields (" +
+                                              std::to_string(need_ck >> 20) + " MiB needed): use fewer shots per call");
+            p.tti_ck_K = K, p.tti_ck_nseg = nseg;
+            if ((rc = dev_alloc(p, &p.tti_ckpt, 2 * fb * 2 * nseg, true))) return rc;
+            if ((rc = dev_alloc(p, &p.tti_seg, 2 * fb * (K + 2), true))) return rc;
+            if (!p.d_wavelet_ck &&
+                (rc = dev_alloc(p, &p.d_wavelet_ck, (size_t)S * nt * std::max(1, p.cfg.nsrc) * sizeof(T), true)))
+                return rc;
+        }
     }
     if (save) p.tti_save_valid = false;
-    const long stride = save ? (long)nt * L.field : 3L * L.field;
-    T *fu = save ? (T *)p.tti_save : (T *)(mode == 0 ? p.tti_fwd : p.tti_adj);
+    const bool ck = save && p.tti_ck_K > 0;
+    if (ck) {
+        MIFWI_HIP(hipMemcpyAsync(p.d_wavelet_ck, p.d_wavelet, (size_t)nshots * nt * std::max(1, p.cfg.nsrc) * sizeof(T),
+                                 hipMemcpyDeviceToDevice, p.stream));
+        p.tti_fwd_valid = false;
+    }
+    const bool in_save = save && !ck;
+    const long stride = in_save ? (long)nt * L.field : 3L * L.field;
+    T *fu = in_save ? (T *)p.tti_save : (T *)(mode == 0 ? p.tti_fwd : p.tti_adj);
     T *fv = fu + S * stride;
-    if (!save) {
+    if (!in_save) {
         MIFWI_HIP(hipMemsetAsync(fu, 0, (size_t)nshots * stride * sizeof(T), p.stream));
         MIFWI_HIP(hipMemsetAsync(fv, 0, (size_t)nshots * stride * sizeof(T), p.stream));
     }   // saved levels 0 and 1 and every halo are never written: they keep the zeros of the allocation
@@ -1722,11 +1807,20 @@ static int tti_run(Plan &p, int nshots, int mode, int save)
         for (int step = 1; step <= nt - 2; ++step) {
             const int time = mode == 0 ? step : nt - 1 - step;
             TtiLevels<T> lv = tti_rot<T>(fu, fv, L.field, time, mode == 0);
-            if (save) {
+            int r;
+            if (in_save) {
                 const long c = (long)time * L.field;
                 lv = TtiLevels<T>{fu + c, fu + c - L.field, fv + c, fv + c - L.field, fu + c + L.field, fv + c + L.field, stride};
             }
-            int r;
+            if (ck && (time - 1) % p.tti_ck_K == 0) {
+                // keep the two levels of u and of v that enter this segment: [field][shot][segment][2]
+                const long cstride = (long)p.tti_ck_nseg * 2 * L.field;
+                T *cu = (T *)p.tti_ckpt + (long)((time - 1) / p.tti_ck_K) * 2 * L.field, *cv = cu + S * cstride;
+                if ((r = copy_levels<T>(p, cu, cstride, lv.uold, stride, 1, nshots))) return r;
+                if ((r = copy_levels<T>(p, cu + L.field, cstride, lv.ucur, stride, 1, nshots))) return r;
+                if ((r = copy_levels<T>(p, cv, cstride, lv.vold, stride, 1, nshots))) return r;
+                if ((r = copy_levels<T>(p, cv + L.field, cstride, lv.vcur, stride, 1, nshots))) return r;
+            }
             if ((r = loop.step(mode == 0, lv, &inj, vals_in, &itp, vals_out, time, launches))) return r;
         }
         return MIFWI_OK;
@@ -1734,13 +1828,10 @@ static int tti_run(Plan &p, int nshots, int mode, int save)
     int launches = 0;
     float ms = 0;
     const auto key = std::make_tuple(4 + mode, nshots, save, 0, 0);
-    if ((rc = timed_loop(p, &key, enqueue, launches, ms, mode == 1))) return rc;
+    if ((rc = timed_loop(p, ck ? nullptr : &key, enqueue, launches, ms, mode == 1))) return rc;
     fill_stats(p, ms, nt - 2, nshots, 2 * 20.0 + 6 * 4.0, launches, mode == 1);
-    if (save) {
-        p.tti_save_valid = true, p.tti_save_shots = nshots;
-    } else {
-        (mode == 0 ? p.tti_fwd_valid : p.tti_adj_valid) = true;
-    }
+    if (save) p.tti_save_valid = true, p.tti_save_shots = nshots;
+    if (!in_save) (mode == 0 ? p.tti_fwd_valid : p.tti_adj_valid) = true;
     return MIFWI_OK;
 }
 
@@ -1833,23 +1924,53 @@ static int tti_gradient(Plan &p, int nshots, const void *residual, void *grad, i
     MIFWI_HIP(hipMemsetAsync(br, 0, (size_t)nshots * stride * sizeof(T), p.stream));
     p.tti_adj_valid = false;
     const T *su = (const T *)p.tti_save, *sv = su + S * sstride;
+    const bool ck = p.tti_ck_K > 0;
     TtiLoop<T> loop(p, nshots);
     if ((rc = loop.prepare(&p.rec, (const T *)p.d_res))) return rc;
+    if (ck && loop.tiled && (rc = prepare_injection<T>(p, p.src, p.d_wavelet_ck, nshots))) return rc;   // recomputation
     auto enqueue = [&](int &launches) -> int {
-        for (int time = nt - 2; time >= 1; --time) {
-            const TtiLevels<T> a = tti_rot<T>(bp, br, L.field, time, false);
-            int r;
-            TtiExtra<T> x{};
-            x.su = su + (long)time * L.field, x.sv = sv + (long)time * L.field, x.level_stride = L.field;
-            x.s_shot_stride = sstride, x.grad = (T *)p.d_grad, x.g_shot_stride = L.field;
-            if ((r = loop.step(false, a, &p.rec, (const T *)p.d_res, nullptr, nullptr, time, launches, &x))) return r;
+        int r;
+        if (!ck) {
+            for (int time = nt - 2; time >= 1; --time) {
+                const TtiLevels<T> a = tti_rot<T>(bp, br, L.field, time, false);
+                TtiExtra<T> x{};
+                x.su = su + (long)time * L.field, x.sv = sv + (long)time * L.field, x.level_stride = L.field;
+                x.s_shot_stride = sstride, x.grad = (T *)p.d_grad, x.g_shot_stride = L.field;
+                if ((r = loop.step(false, a, &p.rec, (const T *)p.d_res, nullptr, nullptr, time, launches, &x))) return r;
+            }
+            return MIFWI_OK;
+        }
+        // checkpointed: walk the segments backwards; each is propagated again into the segment buffers
+        // ([field][shot][K + 2 levels], level i of a segment = time t0 - 1 + i) before the backward steps cross it
+        const int K = p.tti_ck_K;
+        const long seg_stride = (long)(K + 2) * L.field, cstride = (long)p.tti_ck_nseg * 2 * L.field;
+        T *gu = (T *)p.tti_seg, *gv = gu + S * seg_stride;
+        for (int j = p.tti_ck_nseg - 1; j >= 0; --j) {
+            const int t0 = 1 + j * K, t1 = std::min(nt - 2, t0 + K - 1);
+            const T *cu = (const T *)p.tti_ckpt + (long)j * 2 * L.field, *cv = cu + S * cstride;
+            if ((r = copy_levels<T>(p, gu, seg_stride, cu, cstride, 2, nshots))) return r;
+            if ((r = copy_levels<T>(p, gv, seg_stride, cv, cstride, 2, nshots))) return r;
+            for (int time = t0; time <= t1; ++time) {
+                const long c = (long)(time - t0 + 1) * L.field;
+                const TtiLevels<T> lv{gu + c, gu + c - L.field, gv + c, gv + c - L.field, gu + c + L.field, gv + c + L.field,
+                                      seg_stride};
+                if ((r = loop.step(true, lv, &p.src, (const T *)p.d_wavelet_ck, nullptr, nullptr, time, launches))) return r;
+            }
+            for (int time = t1; time >= t0; --time) {
+                const TtiLevels<T> a = tti_rot<T>(bp, br, L.field, time, false);
+                const long c = (long)(time - t0 + 1) * L.field;
+                TtiExtra<T> x{};
+                x.su = gu + c, x.sv = gv + c, x.level_stride = L.field;
+                x.s_shot_stride = seg_stride, x.grad = (T *)p.d_grad, x.g_shot_stride = L.field;
+                if ((r = loop.step(false, a, &p.rec, (const T *)p.d_res, nullptr, nullptr, time, launches, &x))) return r;
+            }
         }
         return MIFWI_OK;
     };
     int launches = 0;
     float ms = 0;
     const auto key = std::make_tuple(7, nshots, 0, 0, 0);
-    if ((rc = timed_loop(p, &key, enqueue, launches, ms, true))) return rc;
+    if ((rc = timed_loop(p, ck ? nullptr : &key, enqueue, launches, ms, true))) return rc;
     fill_stats(p, ms, nt - 2, nshots, 2 * 20.0 + 6 * 4.0 + 2 * 4.0 + 8.0, launches, true);
     p.tti_adj_valid = true;
     if ((rc = deliver_grid<T>(p, p.d_grad, grad, nshots, accumulate))) return rc;
@@ -1905,6 +2026,7 @@ static int read_wavefield(Plan &p, int which, int shot, int first, int count, vo
         nlev = 3;
     } else if (which == 7 || which == 8) {
         if (!p.tti_save_valid || shot >= p.tti_save_shots) return fail(MIFWI_ESTATE, "no saved TTI wavefield for this shot");
+        if (p.tti_ck_K > 0) return fail(MIFWI_ESTATE, "the TTI wavefields are checkpointed, not stored level by level");
         base = (const T *)p.tti_save + ((long)(which - 7) * p.cfg.max_shots + shot) * p.cfg.nt * p.L.field;
         nlev = p.cfg.nt;
     } else {

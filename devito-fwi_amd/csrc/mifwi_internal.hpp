@@ -109,10 +109,12 @@ struct Plan {
 
     void *rot_u = nullptr;                   // [max_shots][3][field] forward rotating buffers
     void *rot_v = nullptr;                   // [max_shots][3][field] adjoint rotating buffers
-    void *saved = nullptr;                   // [nt][max_shots][field] saved forward field (level-major)
+    void *saved = nullptr;                   // [levels][max_shots][field] saved forward field (level-major);
+                                             // levels = nt, or nt - ck_nc when the first steps are checkpointed
     void *ckpt = nullptr;                    // [max_shots][ck_nseg][2][field] levels entering each segment
     void *seg = nullptr;                     // [max_shots][ck_K+2][field] recomputed segment
     int ck_K = 0, ck_nseg = 0;               // segment length (0: every level is stored) and count
+    int ck_nc = 0;                           // steps 1 .. ck_nc are checkpointed; `saved` holds levels ck_nc .. nt-1
     bool saved_valid = false;
     int saved_shots = 0;
     bool rot_u_valid = false, rot_v_valid = false;
@@ -139,6 +141,9 @@ struct Plan {
     bool save_f16 = false;          // saved levels are half precision (MIFWI_FLAG_SAVE_F16 in effect)
     void *d_save_scale = nullptr;   // per shot: stored half = float * scale
     void *tti_save = nullptr;   // every level of both forward fields: [field][shot][nt] (tti_forward with save)
+    void *tti_ckpt = nullptr;   // checkpointed instead: [field][shot][segment][2] levels entering each segment
+    void *tti_seg = nullptr;    // and [field][shot][tti_ck_K + 2] levels of the segment being propagated again
+    int tti_ck_K = 0, tti_ck_nseg = 0;
     bool tti_save_valid = false;
     int tti_save_shots = 0;
     // Injected terms of every time step, formed once before a time loop of the tiled kernels:

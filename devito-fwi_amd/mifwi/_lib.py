@@ -37,7 +37,8 @@ class _Stats(ctypes.Structure):
     _fields_ = [("kernel_ms", ctypes.c_double), ("points", ctypes.c_double), ("gpointss", ctypes.c_double),
                 ("algorithmic_bytes", ctypes.c_double), ("fwd_ms", ctypes.c_double), ("bwd_ms", ctypes.c_double),
                 ("launches", ctypes.c_int32), ("fwd_launches", ctypes.c_int32), ("bwd_launches", ctypes.c_int32),
-                ("kernel_kind", ctypes.c_int32), ("device_bytes", ctypes.c_int64)]
+                ("kernel_kind", ctypes.c_int32), ("device_bytes", ctypes.c_int64), ("ckpt_steps", ctypes.c_int32),
+                ("ckpt_segment", ctypes.c_int32)]
 
 KERNEL_NAMES = {0: ("step_generic_kernel", "step_generic_kernel<GRAD>"),
                 1: ("step2d_kernel", "step2d_kernel<GRAD>"),

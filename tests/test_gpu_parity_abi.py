@@ -300,3 +300,46 @@ def test_l2_misfit_of_given_gathers(mifwi, dtype):
     with pytest.raises(mifwi.MifwiError):
         plan.l2_misfit(syn, obs, nshots=4)
     plan.close()
+
+
+@pytest.mark.parametrize("kind", ["3d", "2d-generic"])
+def test_partly_checkpointed_gradient_is_bit_identical(mifwi, kind, monkeypatch):
+    """When only part of the saved wavefield fits, the first steps are checkpointed and the rest stored level
+    by level (MIFWI_SAVE_BUDGET_MB stands in for a full GPU): same gradient bits as the full save, for a
+    range of budgets, hence of split points and segment lengths."""
+    if kind == "3d":
+        case = Case((20, 18, 22), (10.0, 10.0, 10.0), nbl=6, space_order=8, nt=97, nshots=2, nrec=12, seed=21)
+        flags = 0
+    else:
+        case = Case((50, 44), (10.0, 10.0), nbl=8, space_order=8, nt=131, nshots=2, nrec=15, seed=22)
+        flags = 4
+    full = case.plan(mifwi, flags=flags)
+    rec = full.forward(case.wavelet, save=True)
+    g_full, il_full = full.gradient(rec, want_illum=True)
+    st = full.stats()
+    assert st["ckpt_steps"] == 0
+    full.close()
+    # bytes of one time level of the batch as the library lays it out: halo of R in every dimension, rows padded
+    # to 32 elements with a left z halo rounded up to 4
+    n = (1,) * (3 - case.ndim) + tuple(case.prob.shape_pad)
+    R = case.prob.space_order // 2
+    zl = (R + 3) // 4 * 4
+    pitch = (zl + (n[2] + 3) // 4 * 4 + zl + 31) // 32 * 32
+    rows = n[1] + (2 * R if case.ndim >= 2 else 0)
+    planes = n[0] + (2 * R if case.ndim >= 3 else 0)
+    level_mb = case.nshots * (pitch * rows * planes + 288) * 4 / 2 ** 20
+    seen = set()
+    for frac in (0.85, 0.7, 0.55):
+        monkeypatch.setenv("MIFWI_SAVE_BUDGET_MB", str(max(1, int(np.ceil(level_mb * case.nt * frac)))))
+        part = case.plan(mifwi, flags=flags)
+        rec2 = part.forward(case.wavelet, save=True)
+        g, il = part.gradient(rec2, want_illum=True)
+        st = part.stats()
+        assert 0 < st["ckpt_steps"] < case.nt - 2, (frac, st["ckpt_steps"], st["ckpt_segment"])
+        seen.add(st["ckpt_steps"])
+        assert np.array_equal(rec, rec2)
+        assert np.array_equal(g_full, g) and np.array_equal(il_full, il), (frac, st["ckpt_steps"], st["ckpt_segment"])
+        out = part.l2_misfit_gradient(case.wavelet, 0.5 * rec)
+        assert np.isfinite(out["fval"]).all() and np.abs(out["grad"]).max() > 0
+        part.close()
+    assert len(seen) >= 2

@@ -217,3 +217,34 @@ def test_tti_solver_jacobian_pair():
     acc.data[...] = g.data
     g2, _ = solver.jacobian_adjoint(res, u, v, dm=acc)          # host copies: fields are modelled again
     assert g2 is acc and rel_l2(acc.data, 2 * g.data) <= 1e-6
+
+
+@pytest.mark.parametrize("shape,so,flags", [((70, 48), 8, 0), ((53, 40), 8, 4), ((19, 17, 21), 4, 0)])
+def test_tti_checkpointed_gradient_is_bit_identical(mifwi, shape, so, flags):
+    """mifwi_tti_forward(save=1) keeps two levels of u and v per segment when every level does not fit (forced here
+    with MIFWI_FLAG_CHECKPOINT) and mifwi_tti_gradient propagates each segment again before crossing it: the
+    same kernels in the same order, hence the same gradient bits as with every level stored
+    (seismic/tti/wavesolver.py:282-357 is the reference's checkpointed counterpart).  Tiled 2-D, untiled 2-D, 3-D."""
+    prob, vp, src, rec, rng = tti_case(shape, so=so, dtype=np.float32)
+    dt = float(prob.critical_dt)
+    nt = 83 if len(shape) == 2 else 41
+    w = orc.ricker(0.03, dt * np.arange(nt)).reshape(nt, 1).astype(np.float32)
+    src, rec = src.astype(np.float32), rec.astype(np.float32)
+    res = rng.standard_normal((1, nt, rec.shape[0])).astype(np.float32)
+    out = {}
+    for name, fl in (("full", flags), ("ckpt", flags | mifwi.FLAG_CHECKPOINT)):
+        plan = mifwi.Plan(prob.shape_pad, prob.spacing, prob.origin_pad, prob.space_order, nt, dt, 1, rec.shape[0],
+                          max_shots=1, dtype=np.float32, flags=fl)
+        plan.set_model(prob.vp, prob.damp)
+        plan.tti_set_model(prob.epsilon, prob.delta, prob.theta, prob.phi)
+        plan.set_geometry(src.reshape(1, 1, -1), rec)
+        d = plan.tti_forward(w, save=True)
+        if name == "ckpt":
+            plan.tti_forward(2.0 * w[::-1].copy())        # other modelling in between must not disturb the checkpoints
+            with pytest.raises(mifwi.MifwiError):
+                plan.read_wavefield(7)                    # levels are not stored one by one
+        out[name] = (d, plan.tti_gradient(res))
+        plan.close()
+    assert np.array_equal(out["full"][0], out["ckpt"][0])
+    assert np.abs(out["full"][1]).max() > 0
+    assert np.array_equal(out["full"][1], out["ckpt"][1])

@@ -166,9 +166,9 @@ __global__ __launch_bounds__(256) void step2(Args a)
     *reinterpret_cast<float4 *>(out2 + gidx(x, z)) = make_float4(res[0], res[1], res[2], res[3]);
 }
 
-int main()
+int main(int argc, char **argv)
 {
-    const int shots = 8, steps = 1500;
+    const int shots = argc > 1 ? atoi(argv[1]) : 8, steps = 1500;   // batch size: 8 fills the GPU, 1-4 do not
     const size_t fb = (size_t)shots * FIELD * sizeof(float);
     float *lv[4], *ref[3], *m, *eta;
     for (auto &p : lv) { CK(hipMalloc(&p, fb)); }
@@ -237,7 +237,7 @@ int main()
         }
         // final level = index (steps + 1)
         CK(hipMemcpy((variant == 0 ? r1 : r2).data(), L[(steps + 1) % nl], fb, hipMemcpyDeviceToHost));
-        printf("%s: %.3f ms for %d steps = %.3f us per time step\n", variant == 0 ? "one step per launch " : "two steps per launch",
+        printf("%d shots, %s: %.3f ms for %d steps = %.3f us per time step\n", shots, variant == 0 ? "one step per launch " : "two steps per launch",
                best, steps, best * 1e3 / steps);
         CK(hipGraphExecDestroy(ge)); CK(hipGraphDestroy(g));
     }
