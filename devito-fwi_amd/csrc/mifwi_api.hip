@@ -515,6 +515,7 @@ static int create(const mifwi_config *cfg, mifwi_plan **out)
         p->bpc_fwd = step3d_blocks_per_cu(p->L.R, false);
         p->bpc_grad = step3d_blocks_per_cu(p->L.R, true);
         if (const char *env = getenv("MIFWI_3D_NCHUNK")) p->nchunk_env = std::max(1, atoi(env));  // tuning experiments
+        if (cfg->flags & MIFWI_FLAG_TIME_BLOCK) p->slab_w = 64, p->slab_chunks = 2;   // the best measured at 592^3
         if (const char *env = getenv("MIFWI_3D_SLAB")) p->slab_w = atoi(env);                      // tuning experiments
         if (const char *env = getenv("MIFWI_3D_SLAB_CHUNKS")) p->slab_chunks = std::max(1, atoi(env));
         if (p->slab_w > 0 && p->slab_w < 2 * p->L.R) p->slab_w = 2 * p->L.R;

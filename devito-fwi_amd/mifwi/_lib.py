@@ -8,6 +8,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 F32, F64 = 0, 1
 FLAG_ASYNC, FLAG_NO_GRAPH, FLAG_GENERIC, FLAG_CHECKPOINT, FLAG_FREE_SURFACE, FLAG_OT4 = 1, 2, 4, 8, 16, 32
 FLAG_SAVE_F16 = 64
+FLAG_TIME_BLOCK = 128
 
 # every symbol include/mifwi.h declares
 EXPORTED_SYMBOLS = (
