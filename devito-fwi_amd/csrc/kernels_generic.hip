@@ -380,6 +380,101 @@ template int launch_sparse<float>(const Plan &, const SparsePtrs<float> &, int);
 template int launch_sparse<double>(const Plan &, const SparsePtrs<double> &, int);
 
 // ------------------------------------------------------------------------------------------
+// Perfectly matched layer, 2-D (Grote and Sim; discretised as seismic/abc_methods/03_pml.ipynb cells 75-76
+// of the reference).  u lives on the nodes, phi1 and phi2 on the points half a cell further in x and z
+// (array index (x, z) = point (x + 1/2, z + 1/2)).  With s = zeta_x + zeta_z:
+//   u[t+1] (1 + s dt/2) = 2 u[t] - u[t-1] (1 - s dt/2)
+//                         + dt^2 ( L(u[t]) / m - zeta_x zeta_z u[t] - P1 - P2 )
+//   P1 = -(1/2hx) (phi1[x,z-1] + phi1[x,z] - phi1[x-1,z-1] - phi1[x-1,z])
+//   P2 = -(1/2hz) (phi2[x-1,z] + phi2[x,z] - phi2[x-1,z-1] - phi2[x,z-1])
+//   phi1[t+1] (1/dt + zx/2) = phi1[t] (1/dt - zx/2) + (zz - zx) c^2 (1/4hx) (a(u[t+1]) + a(u[t]))
+//   phi2[t+1] (1/dt + zz/2) = phi2[t] (1/dt - zz/2) + (zx - zz) c^2 (1/4hz) (b(u[t+1]) + b(u[t]))
+//   a(u) = u[x+1,z] + u[x+1,z+1] - u[x,z] - u[x,z+1],  b(u) = u[x,z+1] + u[x+1,z+1] - u[x,z] - u[x+1,z]
+// with zx, zz, c^2 of the phi equations taken at the staggered point (c^2: mean of 1/m over the cell's
+// corners inside the grid).  Fields are zero outside the grid (halo), as everywhere in this library.
+// ------------------------------------------------------------------------------------------
+template <typename T, int R>
+__global__ __launch_bounds__(256) void pml_u_kernel(StepConsts<T> k, PmlPtrs<T> q)
+{
+    const int i2 = blockIdx.x * 64 + threadIdx.x;
+    const int i1 = blockIdx.y * 4 + threadIdx.y;
+    const int shot = blockIdx.z;
+    if (i2 >= k.n2 || i1 >= k.n1) return;
+    const long p = k.off0 + (long)i1 * k.s1 + i2;
+    const T *cur = q.cur + (long)shot * q.shot_stride + p;
+    const T lap = star<T, R, 2>(k, cur);
+    const T uc = cur[0], uo = q.old[(long)shot * q.shot_stride + p];
+    const T *f1 = q.phi1 + (long)shot * q.phi_shot_stride + p, *f2 = q.phi2 + (long)shot * q.phi_shot_stride + p;
+    const T P1 = -T(0.5) * q.ihx * (f1[-1] + f1[0] - f1[-k.s1 - 1] - f1[-k.s1]);
+    const T P2 = -T(0.5) * q.ihz * (f2[-k.s1] + f2[0] - f2[-k.s1 - 1] - f2[-1]);
+    const T zx = q.zx0[i1], zz = q.zz0[i2];
+    const T h = T(0.5) * (zx + zz) * k.dt;
+    const T rhs = T(2) * uc - uo * (T(1) - h) + k.dt2 * (lap / q.m[p] - zx * zz * uc - P1 - P2);
+    q.out[(long)shot * q.shot_stride + p] = rhs / (T(1) + h);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void pml_phi_kernel(StepConsts<T> k, PmlPtrs<T> q)
+{
+    const int i2 = blockIdx.x * 64 + threadIdx.x;
+    const int i1 = blockIdx.y * 4 + threadIdx.y;
+    const int shot = blockIdx.z;
+    if (i2 >= k.n2 || i1 >= k.n1) return;
+    const long p = k.off0 + (long)i1 * k.s1 + i2;
+    const T zx = q.zx1[i1], zz = q.zz1[i2];
+    const long ps = (long)shot * q.phi_shot_stride + p;
+    if (zx == T(0) && zz == T(0)) {   // outside the layer the auxiliary fields stay zero
+        q.phi1_out[ps] = T(0), q.phi2_out[ps] = T(0);
+        return;
+    }
+    const T *un = q.out + (long)shot * q.shot_stride + p, *uc = q.cur + (long)shot * q.shot_stride + p;
+    const long sx = k.s1;
+    const T a = (un[sx] + un[sx + 1] - un[0] - un[1]) + (uc[sx] + uc[sx + 1] - uc[0] - uc[1]);
+    const T b = (un[1] + un[sx + 1] - un[0] - un[sx]) + (uc[1] + uc[sx + 1] - uc[0] - uc[sx]);
+    // c^2 at the staggered point: mean over the corners of the cell that lie inside the grid
+    const bool xin = i1 + 1 < k.n1, zin = i2 + 1 < k.n2;
+    T c2 = T(1) / q.m[p];
+    int nc = 1;
+    if (xin) c2 += T(1) / q.m[p + sx], ++nc;
+    if (zin) c2 += T(1) / q.m[p + 1], ++nc;
+    if (xin && zin) c2 += T(1) / q.m[p + sx + 1], ++nc;
+    c2 /= T(nc);
+    const T idt = T(1) / k.dt;
+    q.phi1_out[ps] = (q.phi1[ps] * (idt - T(0.5) * zx) + (zz - zx) * c2 * T(0.25) * q.ihx * a) / (idt + T(0.5) * zx);
+    q.phi2_out[ps] = (q.phi2[ps] * (idt - T(0.5) * zz) + (zx - zz) * c2 * T(0.25) * q.ihz * b) / (idt + T(0.5) * zz);
+}
+
+template <typename T>
+int launch_pml_u(const Plan &p, const StepConsts<T> &k, const PmlPtrs<T> &q, int nshots)
+{
+    const dim3 block(64, 4, 1), grid((k.n2 + 63) / 64, (k.n1 + 3) / 4, (unsigned)nshots);
+    switch (p.L.R) {
+        case 1: hipLaunchKernelGGL((pml_u_kernel<T, 1>), grid, block, 0, p.stream, k, q); break;
+        case 2: hipLaunchKernelGGL((pml_u_kernel<T, 2>), grid, block, 0, p.stream, k, q); break;
+        case 3: hipLaunchKernelGGL((pml_u_kernel<T, 3>), grid, block, 0, p.stream, k, q); break;
+        case 4: hipLaunchKernelGGL((pml_u_kernel<T, 4>), grid, block, 0, p.stream, k, q); break;
+        case 5: hipLaunchKernelGGL((pml_u_kernel<T, 5>), grid, block, 0, p.stream, k, q); break;
+        case 6: hipLaunchKernelGGL((pml_u_kernel<T, 6>), grid, block, 0, p.stream, k, q); break;
+        case 7: hipLaunchKernelGGL((pml_u_kernel<T, 7>), grid, block, 0, p.stream, k, q); break;
+        default: hipLaunchKernelGGL((pml_u_kernel<T, 8>), grid, block, 0, p.stream, k, q);
+    }
+    MIFWI_HIP(hipGetLastError());
+    return MIFWI_OK;
+}
+template <typename T>
+int launch_pml_phi(const Plan &p, const StepConsts<T> &k, const PmlPtrs<T> &q, int nshots)
+{
+    const dim3 block(64, 4, 1), grid((k.n2 + 63) / 64, (k.n1 + 3) / 4, (unsigned)nshots);
+    hipLaunchKernelGGL((pml_phi_kernel<T>), grid, block, 0, p.stream, k, q);
+    MIFWI_HIP(hipGetLastError());
+    return MIFWI_OK;
+}
+template int launch_pml_u<float>(const Plan &, const StepConsts<float> &, const PmlPtrs<float> &, int);
+template int launch_pml_u<double>(const Plan &, const StepConsts<double> &, const PmlPtrs<double> &, int);
+template int launch_pml_phi<float>(const Plan &, const StepConsts<float> &, const PmlPtrs<float> &, int);
+template int launch_pml_phi<double>(const Plan &, const StepConsts<double> &, const PmlPtrs<double> &, int);
+
+// ------------------------------------------------------------------------------------------
 // dense <-> haloed copies and model preparation
 // ------------------------------------------------------------------------------------------
 struct DenseMap {

@@ -164,6 +164,8 @@ static void destroy(Plan *p)
     dev_free(p->d_grad);
     dev_free(p->d_illum);
     dev_free(p->d_dm);
+    dev_free(p->pml_phi);
+    dev_free(p->pml_zeta);
     dev_free(p->d_winj[0]);
     dev_free(p->d_winj[1]);
     dev_free(p->tti_par);
@@ -457,6 +459,11 @@ static int validate(const mifwi_config &c)
     if (c.max_shots < 1) return fail(MIFWI_EINVAL, "max_shots must be at least 1");
     if ((c.flags & MIFWI_FLAG_OT4) && (c.flags & MIFWI_FLAG_FREE_SURFACE))
         return fail(MIFWI_EINVAL, "the OT4 kernel is not available with a free surface");
+    if (c.flags & MIFWI_FLAG_PML) {
+        if (c.ndim != 2) return fail(MIFWI_EINVAL, "the perfectly matched layer is available for 2-D grids only");
+        if (c.flags & (MIFWI_FLAG_OT4 | MIFWI_FLAG_FREE_SURFACE))
+            return fail(MIFWI_EINVAL, "the perfectly matched layer is not combinable with OT4 or a free surface");
+    }
     return MIFWI_OK;
 }
 
@@ -491,7 +498,7 @@ static int create(const mifwi_config *cfg, mifwi_plan **out)
     if (const char *env = getenv("MIFWI_PAIR_GRAD")) p->pair_grad = atoi(env);  // tuning experiments
     if (const char *env = getenv("MIFWI_PAIR_SAVE")) p->pair_save = atoi(env);  // tuning experiments
     if (const char *env = getenv("MIFWI_2D_VEC")) p->vec2d = atoi(env);  // tuning experiments
-    if (cfg->ndim == 2 && cfg->dtype == MIFWI_F32 && !(cfg->flags & (MIFWI_FLAG_GENERIC | MIFWI_FLAG_OT4))) {
+    if (cfg->ndim == 2 && cfg->dtype == MIFWI_F32 && !(cfg->flags & (MIFWI_FLAG_GENERIC | MIFWI_FLAG_OT4 | MIFWI_FLAG_PML))) {
         // tiled fast path: pick the tile shape that wastes fewer threads on this grid
         const int n1 = p->L.n[1], n2 = p->L.n[2];
         auto waste = [&](int tx, int tz) { return (double)((n1 + tx - 1) / tx * tx) * ((n2 + tz - 1) / tz * tz); };
@@ -540,6 +547,10 @@ static int create(const mifwi_config *cfg, mifwi_plan **out)
     if ((rc = dev_alloc(*p, &p->eta, field * es, true))) return bail(rc);
     if ((rc = dev_alloc(*p, &p->rot_u, S * 3 * field * es, true))) return bail(rc);
     if ((rc = dev_alloc(*p, &p->rot_v, S * 3 * field * es, true))) return bail(rc);
+    if (cfg->flags & MIFWI_FLAG_PML) {
+        if ((rc = dev_alloc(*p, &p->pml_phi, S * 4 * field * es, true))) return bail(rc);
+        if ((rc = dev_alloc(*p, &p->pml_zeta, 2 * (size_t)(p->L.n[1] + p->L.n[2]) * es, true))) return bail(rc);
+    }
     if (cfg->flags & MIFWI_FLAG_OT4) {
         if ((rc = dev_alloc(*p, &p->d_t4, S * field * es, true))) return bail(rc);
         if ((rc = dev_alloc(*p, &p->d_w2, S * field * es, true))) return bail(rc);
@@ -607,6 +618,13 @@ static int set_geometry(Plan &p, int nshots, const void *src_coords, const void 
         return rc;
     p.have_geometry = true;
     p.geom_shots = nshots;
+    return MIFWI_OK;
+}
+
+static int no_pml(const Plan &p)
+{
+    if (p.cfg.flags & MIFWI_FLAG_PML)
+        return fail(MIFWI_EINVAL, "only mifwi_forward is available on a perfectly matched layer plan");
     return MIFWI_OK;
 }
 
@@ -1429,12 +1447,20 @@ static int deliver_grid(Plan &p, const void *haloed, void *user, int nshots, int
 }
 
 template <typename T>
+static int run_forward_pml(Plan &p, int nshots);
+
+template <typename T>
 static int forward(Plan &p, int nshots, const void *wavelet, int per_shot, void *rec_out, int save)
 {
     int rc;
     if ((rc = check_run(p, nshots))) return rc;
     if ((rc = upload_wavelet<T>(p, nshots, wavelet, per_shot))) return rc;
-    if ((rc = run_forward<T>(p, nshots, save))) return rc;
+    if (p.cfg.flags & MIFWI_FLAG_PML) {
+        if (save) return fail(MIFWI_EINVAL, "a perfectly matched layer plan models without saving the wavefield");
+        if ((rc = run_forward_pml<T>(p, nshots))) return rc;
+    } else if ((rc = run_forward<T>(p, nshots, save))) {
+        return rc;
+    }
     if (rec_out && (rc = copy_any(p, rec_out, p.d_rec, (size_t)nshots * p.cfg.nt * p.cfg.nrec * sizeof(T)))) return rc;
     return finish(p);
 }
@@ -1444,6 +1470,7 @@ template <typename T>
 static int born(Plan &p, int nshots, const void *wavelet, int per_shot, const void *dm, void *rec_out)
 {
     int rc;
+    if (int e = no_pml(p)) return e;
     if ((rc = check_run(p, nshots))) return rc;
     if (!dm) return fail(MIFWI_EINVAL, "dm is null");
     if ((rc = upload_wavelet<T>(p, nshots, wavelet, per_shot))) return rc;
@@ -1487,6 +1514,7 @@ template <typename T>
 static int adjoint(Plan &p, int nshots, const void *rec_in, void *srca_out)
 {
     int rc;
+    if (int e = no_pml(p)) return e;
     if ((rc = check_run(p, nshots))) return rc;
     if (!rec_in) return fail(MIFWI_EINVAL, "rec_in is null");
     if ((rc = copy_any(p, p.d_res, rec_in, (size_t)nshots * p.cfg.nt * p.cfg.nrec * sizeof(T)))) return rc;
@@ -1499,6 +1527,7 @@ template <typename T>
 static int gradient(Plan &p, int nshots, const void *residual, void *grad, int accumulate, void *illum)
 {
     int rc;
+    if (int e = no_pml(p)) return e;
     if ((rc = check_run(p, nshots))) return rc;
     if (!residual || !grad) return fail(MIFWI_EINVAL, "residual or grad is null");
     if ((rc = copy_any(p, p.d_res, residual, (size_t)nshots * p.cfg.nt * p.cfg.nrec * sizeof(T)))) return rc;
@@ -1513,6 +1542,7 @@ static int l2_misfit_gradient(Plan &p, int nshots, const void *wavelet, int per_
                               void *grad, void *illum, void *residual_out, void *syn_out)
 {
     int rc;
+    if ((rc = no_pml(p))) return rc;
     if ((rc = check_run(p, nshots))) return rc;
     if (!obs) return fail(MIFWI_EINVAL, "obs is null");
     const size_t dbytes = (size_t)nshots * p.cfg.nt * p.cfg.nrec * sizeof(T);
@@ -1547,6 +1577,84 @@ static int l2_misfit_gradient(Plan &p, int nshots, const void *wavelet, int per_
     p.stats.launches = launches;
     p.timing_sum = true;   // asynchronous plans: kernel_ms = forward + backward once both are known
     return finish(p);
+}
+
+// Damping profiles of the perfectly matched layer (fdamp of seismic/abc_methods/03_pml.ipynb cell 60): along a
+// dimension of n nodes, a = depth into the npml-cell layer / its width at node i and at the staggered point i + 1/2
+template <typename T>
+static int set_pml(Plan &p, int npml, double quibar)
+{
+    if (!(p.cfg.flags & MIFWI_FLAG_PML)) return fail(MIFWI_ESTATE, "the plan was not created with MIFWI_FLAG_PML");
+    if (npml < 1 || 2 * npml >= std::min(p.L.n[1], p.L.n[2]) || !(quibar >= 0.0))
+        return fail(MIFWI_EINVAL, "npml must be positive and leave an interior; quibar must not be negative");
+    const int n1 = p.L.n[1], n2 = p.L.n[2];
+    std::vector<T> z(2 * (size_t)(n1 + n2));
+    auto zeta = [&](double pos, int n) {   // pos: node coordinate in cells
+        double a = 0.0;
+        if (pos <= npml) a = (npml - pos) / npml;
+        else if (pos >= n - 1 - npml) a = (pos - (n - 1 - npml)) / npml;
+        return (T)(quibar * (a - std::sin(2.0 * M_PI * a) / (2.0 * M_PI)));
+    };
+    for (int i = 0; i < n1; ++i) z[i] = zeta(i, n1), z[n1 + n2 + i] = zeta(i + 0.5, n1);
+    for (int i = 0; i < n2; ++i) z[n1 + i] = zeta(i, n2), z[2 * n1 + n2 + i] = zeta(i + 0.5, n2);
+    MIFWI_HIP(hipMemcpyAsync(p.pml_zeta, z.data(), z.size() * sizeof(T), hipMemcpyHostToDevice, p.stream));
+    MIFWI_HIP(hipStreamSynchronize(p.stream));
+    clear_graphs(p);
+    p.have_pml = true;
+    return MIFWI_OK;
+}
+
+// forward time loop of a MIFWI_FLAG_PML plan: per step the displacement update, the sparse terms (source into
+// u[t+1], receivers sample u[t]) and the auxiliary-field update, in the order the reference's notebook gives its
+// operator (03_pml.ipynb cell 85)
+template <typename T>
+static int run_forward_pml(Plan &p, int nshots)
+{
+    if (!p.have_pml) return fail(MIFWI_ESTATE, "mifwi_set_pml has not been called");
+    const Layout &L = p.L;
+    const int nt = p.cfg.nt;
+    T *base = (T *)p.rot_u;
+    const long shot_stride = 3L * L.field, phi_stride = 4L * L.field;
+    MIFWI_HIP(hipMemsetAsync(base, 0, (size_t)nshots * shot_stride * sizeof(T), p.stream));
+    MIFWI_HIP(hipMemsetAsync(p.pml_phi, 0, (size_t)nshots * phi_stride * sizeof(T), p.stream));
+    MIFWI_HIP(hipMemsetAsync(p.d_rec, 0, (size_t)nshots * nt * p.cfg.nrec * sizeof(T), p.stream));
+    p.rot_u_valid = false;
+    const StepConsts<T> k = make_consts<T>(p);
+    const T *z = (const T *)p.pml_zeta;
+    const int n1 = L.n[1], n2 = L.n[2];
+    T *phi = (T *)p.pml_phi;
+    auto enqueue = [&](int &launches) -> int {
+        for (int time = 1; time <= nt - 2; ++time) {
+            PmlPtrs<T> q{};
+            q.cur = base + (long)(time % 3) * L.field, q.old = base + (long)((time + 2) % 3) * L.field;
+            q.out = base + (long)((time + 1) % 3) * L.field;
+            q.shot_stride = shot_stride, q.m = (const T *)p.m;
+            q.zx0 = z, q.zz0 = z + n1, q.zx1 = z + n1 + n2, q.zz1 = z + 2 * n1 + n2;
+            const long in = (long)(time & 1) * L.field, on = (long)((time + 1) & 1) * L.field;
+            q.phi1 = phi + in, q.phi2 = phi + 2 * L.field + in;
+            q.phi1_out = phi + on, q.phi2_out = phi + 2 * L.field + on;
+            q.phi_shot_stride = phi_stride;
+            q.ihx = (T)(1.0 / p.cfg.spacing[0]), q.ihz = (T)(1.0 / p.cfg.spacing[1]);
+            int r;
+            if ((r = launch_pml_u<T>(p, k, q, nshots))) return r;
+            SparsePtrs<T> sq{};
+            sq.inj = &p.src, sq.field_inj = q.out, sq.vals_inj = (const T *)p.d_wavelet;
+            sq.itp = &p.rec, sq.field_int = q.cur, sq.vals_out = (T *)p.d_rec;
+            sq.shot_stride = shot_stride, sq.m = (const T *)p.m, sq.time = time, sq.nt = nt, sq.dt2 = k.dt2;
+            if ((r = launch_sparse<T>(p, sq, nshots))) return r;
+            if ((r = launch_pml_phi<T>(p, k, q, nshots))) return r;
+            launches += 3;
+        }
+        return MIFWI_OK;
+    };
+    int launches = 0, rc;
+    float ms = 0;
+    const auto key = std::make_tuple(8, nshots, 0, 0, 0);
+    if ((rc = timed_loop(p, &key, enqueue, launches, ms))) return rc;
+    // displacement 16 B (u[t], u[t-1], m in, u[t+1] out) + in the layer the two auxiliary fields in and out
+    fill_stats(p, ms, nt - 2, nshots, 16.0, launches, false);
+    p.rot_u_valid = true;
+    return MIFWI_OK;
 }
 
 // Least-squares misfit of data already modelled (misfit/misfit.py:5-9): residual = syn - obs,
@@ -1594,6 +1702,7 @@ static int l2_misfit_noalloc(int nshots, long n, const void *syn, const void *ob
 template <typename T>
 static int tti_set_model(Plan &p, const void *eps, const void *delta, const void *theta, const void *phi)
 {
+    if (int e = no_pml(p)) return e;
     if (p.cfg.ndim < 2) return fail(MIFWI_EINVAL, "TTI needs a 2-D or 3-D grid");
     if (p.cfg.space_order % 4) return fail(MIFWI_EINVAL, "TTI needs space_order divisible by 4");
     if (p.cfg.flags & (MIFWI_FLAG_FREE_SURFACE | MIFWI_FLAG_OT4))
@@ -2201,6 +2310,12 @@ int mifwi_l2_misfit_gradient(mifwi_plan *plan, int32_t nshots, const void *wavel
     GUARDED(DISPATCH(
         l2_misfit_gradient<float>(p, nshots, wavelet, wavelet_per_shot, obs, fval, grad, illum, residual_out, syn_out),
         l2_misfit_gradient<double>(p, nshots, wavelet, wavelet_per_shot, obs, fval, grad, illum, residual_out, syn_out)));
+}
+
+int mifwi_set_pml(mifwi_plan *plan, int32_t npml, double quibar)
+{
+    PLAN_OR_FAIL(plan);
+    GUARDED(DISPATCH(set_pml<float>(p, npml, quibar), set_pml<double>(p, npml, quibar)));
 }
 
 int mifwi_l2_misfit(mifwi_plan *plan, int32_t nshots, const void *syn, const void *obs, void *residual_out, double *fval)

@@ -151,6 +151,10 @@ struct Plan {
     // kernels walk the cells (tile-major slots in 2-D, cell_local order in 3-D)
     void *d_winj[2] = {nullptr, nullptr};   // [0]: terms of the sources, [1]: of the receivers
     size_t winj_elems[2] = {0, 0};
+    // MIFWI_FLAG_PML: auxiliary fields [max_shots][phi1 | phi2][2 levels][field] and damping profiles
+    // [zeta_x nodes | zeta_z nodes | zeta_x staggered | zeta_z staggered], n1 + n2 + n1 + n2 values
+    void *pml_phi = nullptr, *pml_zeta = nullptr;
+    bool have_pml = false;
     void *d_dm = nullptr;                    // [field] haloed model perturbation of the Born operator
     void *d_dense = nullptr;                 // dense staging, max(max_shots*ngrid, ...) elements
     size_t dense_elems = 0;
@@ -256,6 +260,24 @@ int launch_inject_prepare(const Plan &p, const SparseSet &S, const int32_t *g_u,
 
 template <typename T>
 int launch_prep_model(const Plan &p, const T *vp_dense, const T *damp_dense, T *m, T *eta);
+
+// 2-D perfectly matched layer (kernels_generic.hip): displacement step and auxiliary-field step of all shots
+template <typename T>
+struct PmlPtrs {
+    const T *cur, *old;      // u[t], u[t-1] (shot 0)
+    T *out;                  // u[t+1]
+    long shot_stride;
+    const T *m;
+    const T *zx0, *zz0, *zx1, *zz1;   // damping profiles along dimension 1 (x) and 2 (z): nodes, staggered points
+    const T *phi1, *phi2;    // auxiliary fields at time t (shot 0)
+    T *phi1_out, *phi2_out;  // and at t+1
+    long phi_shot_stride;
+    T ihx, ihz;              // 1 / spacing
+};
+template <typename T>
+int launch_pml_u(const Plan &p, const StepConsts<T> &k, const PmlPtrs<T> &q, int nshots);
+template <typename T>
+int launch_pml_phi(const Plan &p, const StepConsts<T> &k, const PmlPtrs<T> &q, int nshots);
 
 // dense (nshots, grid) <-> haloed (nshots, field).  mode: 0 dst = src, 1 dst += src
 template <typename T>

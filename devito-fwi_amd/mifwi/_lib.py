@@ -9,6 +9,7 @@ F32, F64 = 0, 1
 FLAG_ASYNC, FLAG_NO_GRAPH, FLAG_GENERIC, FLAG_CHECKPOINT, FLAG_FREE_SURFACE, FLAG_OT4 = 1, 2, 4, 8, 16, 32
 FLAG_SAVE_F16 = 64
 FLAG_TIME_BLOCK = 128
+FLAG_PML = 256
 
 # every symbol include/mifwi.h declares
 EXPORTED_SYMBOLS = (
@@ -17,6 +18,7 @@ EXPORTED_SYMBOLS = (
     "mifwi_gradient", "mifwi_l2_misfit_gradient", "mifwi_read_wavefield", "mifwi_write_wavefield",
     "mifwi_get_stats", "mifwi_born", "mifwi_tti_set_model", "mifwi_tti_forward", "mifwi_tti_adjoint",
     "mifwi_tti_born", "mifwi_tti_gradient", "mifwi_l2_misfit", "mifwi_l2_misfit_noalloc",
+    "mifwi_set_pml",
 )
 
 
@@ -91,6 +93,7 @@ def load_library():
     lib.mifwi_tti_adjoint.argtypes = [vp, i32, vp, vp]
     lib.mifwi_gradient.argtypes = [vp, i32, vp, vp, i32, vp]
     lib.mifwi_l2_misfit_gradient.argtypes = [vp, i32, vp, i32, vp, vp, vp, vp, vp, vp]
+    lib.mifwi_set_pml.argtypes = [vp, i32, ctypes.c_double]
     lib.mifwi_l2_misfit.argtypes = [vp, i32, vp, vp, vp, vp]
     lib.mifwi_l2_misfit_noalloc.argtypes = [i32, i32, ctypes.c_int64, vp, vp, vp, vp, vp]
     lib.mifwi_read_wavefield.argtypes = [vp, i32, i32, i32, i32, vp]
@@ -227,6 +230,10 @@ class Plan(object):
         n = kv.numel() if _is_torch(kv) else kv.size
         assert n == self.ngrid, "vp must cover the padded grid"
         self._check(self._lib.mifwi_set_model(self._h, pv, pd))
+
+    def set_pml(self, npml, quibar=0.05):
+        """Layer width (cells) and strength of a FLAG_PML plan."""
+        self._check(self._lib.mifwi_set_pml(self._h, int(npml), float(quibar)))
 
     def set_geometry(self, src_coords, rec_coords, rec_per_shot=False, nshots=None):
         sc = np.ascontiguousarray(src_coords, dtype=self.dtype)

@@ -47,7 +47,12 @@ class AcousticWaveSolver(object):
 
     def __init__(self, model, geometry, kernel='OT2', space_order=4, **kwargs):
         self.model = model
-        self.model._initialize_bcs(bcs="damp")
+        # the reference forces the sponge here (wavesolver.py:30); a model built with bcs="pml" keeps its choice
+        self._pml = getattr(model, '_bcs', None) == "pml"
+        if not self._pml:
+            self.model._initialize_bcs(bcs="damp")
+        elif model.dim != 2 or kernel != 'OT2' or getattr(model, 'fs', False) or model.nbl < 1:
+            raise NotImplementedError("bcs='pml' is available for 2-D OT2 modelling without a free surface")
         self.geometry = geometry
         assert self.model.grid == geometry.grid
         if kernel not in ('OT2', 'OT4'):
@@ -70,8 +75,9 @@ class AcousticWaveSolver(object):
     def _entry(self, dt, nsrc, nrec, nt):
         from mifwi import engine
         m = self.model
-        from mifwi import FLAG_FREE_SURFACE, FLAG_OT4
+        from mifwi import FLAG_FREE_SURFACE, FLAG_OT4, FLAG_PML
         flags = (FLAG_FREE_SURFACE if getattr(m, 'fs', False) else 0) | (FLAG_OT4 if self.kernel == 'OT4' else 0)
+        flags |= FLAG_PML if self._pml else 0
         return engine.get_plan(m.grid.shape, m.spacing, m.grid.origin, self.space_order, nt, dt, nsrc, nrec,
                                max_shots=1, dtype=m.dtype, device=self._device, flags=flags)
 
@@ -82,7 +88,13 @@ class AcousticWaveSolver(object):
     def _load(self, entry, vp, src_coords, rec_coords):
         vp_arr = np.ascontiguousarray(_as_vp_array(vp, self.model), dtype=self.model.dtype)
         entry.plan.set_model(vp_arr, np.ascontiguousarray(self._damp_array(), dtype=self.model.dtype))
+        if self._pml:
+            entry.plan.set_pml(self.model.nbl)
         entry.plan.set_geometry(src_coords, rec_coords)
+
+    def _no_pml(self):
+        if self._pml:
+            raise NotImplementedError("only forward modelling is available with bcs='pml'")
 
     # -- operators ------------------------------------------------------------------------------
     def forward(self, src=None, rec=None, u=None, vp=None, save=None, **kwargs):
@@ -91,6 +103,8 @@ class AcousticWaveSolver(object):
         rec = rec or self.geometry.rec
         dt = kwargs.pop('dt', self.dt)
         nt = src.data.shape[0]
+        if self._pml and save:
+            raise NotImplementedError("bcs='pml' models without saving the wavefield")
         entry = self._entry(dt, src.data.shape[1], rec.data.shape[1], nt)
         self._load(entry, vp, src.coordinates.data, rec.coordinates.data)
         which = 0 if save else 1
@@ -113,6 +127,7 @@ class AcousticWaveSolver(object):
 
     def adjoint(self, rec, srca=None, v=None, vp=None, **kwargs):
         """Adjoint modelling; returns (srca, v, summary) (wavesolver.py:116-151)."""
+        self._no_pml()
         srca = srca or self.geometry.new_src(name='srca', src_type=None)
         dt = kwargs.pop('dt', self.dt)
         nt = rec.data.shape[0]
@@ -134,6 +149,7 @@ class AcousticWaveSolver(object):
         """Adjoint Jacobian (FWI gradient); accumulates into `grad` and returns (grad, summary)
         (wavesolver.py:153-205).  Extension: a Function passed as `illum` also receives (is incremented
         by) the sum over time of u^2, which the gradient kernel forms from the saved wavefield anyway."""
+        self._no_pml()
         if checkpointing:
             raise NotImplementedError("pyrevolve checkpointing is not available; the saved wavefield stays on the GPU")
         dt = kwargs.pop('dt', self.dt)
@@ -158,6 +174,7 @@ class AcousticWaveSolver(object):
     def jacobian(self, dmin, src=None, rec=None, u=None, U=None, vp=None, **kwargs):
         """Linearised Born modelling for the perturbation `dmin` of 1/vp^2 (array over the padded or
         the physical grid, or a Function); returns (rec, u, U, summary) (wavesolver.py:207-242)."""
+        self._no_pml()
         src = src or self.geometry.src
         rec = rec or self.geometry.rec
         dt = kwargs.pop('dt', self.dt)

@@ -86,7 +86,11 @@ class GenericModel(object):
         if self.nbl == 0:
             self.damp = 1 if bcs == "mask" else 0
             return
-        if callable(bcs):
+        if bcs == "pml":
+            # extension: the absorbing layer is a perfectly matched layer of nbl cells (2-D forward modelling;
+            # seismic/abc_methods/03_pml.ipynb of the reference); the sponge field stays zero
+            self.damp = Function(name="damp", grid=self.grid)
+        elif callable(bcs):
             self.damp = self.damp if isinstance(self.damp, Function) else Function(name="damp", grid=self.grid)
             bcs(self.damp, self.nbl)
         elif self._bcs != bcs or not isinstance(self.damp, Function):

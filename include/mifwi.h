@@ -79,6 +79,15 @@ enum {
                                     default: on MI355X it measured 3 % slower than one sweep per step at 592^3
                                     (the last-level cache serves reads only ~1.5x faster than HBM and the slab
                                     launches add fill and drain time).                                          */
+    MIFWI_FLAG_PML = 256,        /* 2-D forward modelling with a perfectly matched layer instead of the sponge: the
+                                    second-order formulation of Grote and Sim with two auxiliary fields on the
+                                    staggered grid, discretised as seismic/abc_methods/03_pml.ipynb (cells 2, 60,
+                                    75-85) of the reference does it, here with the Laplacian at the plan's space
+                                    order and the layer on all four sides (mifwi_set_pml).  `damp` of mifwi_set_model
+                                    is ignored.  Untiled kernels; mifwi_forward without saving only (the adjoint and
+                                    the gradient of this scheme are not part of the library).  The reference holds
+                                    no result of the hot path with this boundary: parity is against the CPU
+                                    restatement only.                                                           */
     MIFWI_FLAG_SAVE_F16 = 64     /* keep the saved forward wavefield (mifwi_forward(save=1)) in IEEE
                                     half precision, scaled per shot from the injected source terms:
                                     half the memory (nt levels of a 592^3 grid fit one GPU) and half
@@ -196,6 +205,12 @@ MIFWI_API int mifwi_gradient(mifwi_plan *plan, int32_t nshots, const void *resid
 MIFWI_API int mifwi_l2_misfit_gradient(mifwi_plan *plan, int32_t nshots, const void *wavelet,
                              int32_t wavelet_per_shot, const void *obs, double *fval, void *grad,
                              void *illum, void *residual_out, void *syn_out);
+
+/* Layer of a MIFWI_FLAG_PML plan: `npml` grid cells on each side of both dimensions, damping functions
+ * zeta_d = quibar * (a - sin(2 pi a) / (2 pi)), a = depth into the layer / layer width (fdamp of
+ * seismic/abc_methods/03_pml.ipynb cell 60, where quibar = 0.05), evaluated at the nodes and at the
+ * half-way (staggered) points.  Must be called before mifwi_forward. */
+MIFWI_API int mifwi_set_pml(mifwi_plan *plan, int32_t npml, double quibar);
 
 /* Replaces: least_square(syn, obs) of misfit/misfit.py:5-9 as fwi.py:151 calls it between the forward and the
  * gradient pass, on gathers that are already on the device: residual_out = syn - obs and

@@ -399,3 +399,113 @@ def fwi_obj_multi(prob, src_positions, rec_pos, wavelet, obs_list, dt=None, mask
         if mask is not None:
             grad *= mask
     return fval, grad.reshape(-1).astype(np.float64), residuals
+
+
+# ----------------------------------------------------------------------------------------------
+# Perfectly matched layer (2-D): numpy restatement of seismic/abc_methods/03_pml.ipynb
+# (PDE cell 2, damping function cell 60, discrete equations cells 75-76, operator order cell 85),
+# generalised to a layer on all four sides and to the Laplacian of any even space order.
+# The reference holds no number of the acoustic hot path with this boundary (the notebook's own last
+# cell only bounds ||rec|| to within a factor of two): parity of the GPU path is against this
+# restatement, which is itself constrained by properties (tests/test_pml.py).
+# ----------------------------------------------------------------------------------------------
+def pml_profiles(n, npml, quibar=0.05):
+    """zeta at the nodes and at the staggered points of a dimension of n nodes (fdamp, cell 60)."""
+    def zeta(pos):
+        a = np.where(pos <= npml, (npml - pos) / npml, np.where(pos >= n - 1 - npml, (pos - (n - 1 - npml)) / npml, 0.0))
+        return quibar * (a - np.sin(2 * np.pi * a) / (2 * np.pi))
+    i = np.arange(n, dtype=np.float64)
+    return zeta(i), zeta(i + 0.5)
+
+
+def _support_2d(coords, origin, spacing, shape, dtype):
+    """(index pairs, weights) of the bilinear support of each point, in the grid dtype as the generated code
+    computes it (sa_01_iso_implementation1.ipynb:1255-1316); corners outside the grid are dropped."""
+    out = []
+    t = np.dtype(dtype).type
+    for c in np.asarray(coords, dtype=dtype).reshape(-1, 2):
+        pts = []
+        pos = [t(c[d]) - t(origin[d]) for d in range(2)]
+        idx = [int(np.floor(pos[d] / t(spacing[d]))) for d in range(2)]
+        frac = [(pos[d] - t(spacing[d]) * t(idx[d])) / t(spacing[d]) for d in range(2)]
+        for bx in (0, 1):
+            for bz in (0, 1):
+                i, j = idx[0] + bx, idx[1] + bz
+                w = (frac[0] if bx else t(1) - frac[0]) * (frac[1] if bz else t(1) - frac[1])
+                if 0 <= i < shape[0] and 0 <= j < shape[1]:
+                    pts.append((i, j, t(w)))
+        out.append(pts)
+    return out
+
+
+def pml_forward(vp_pad, spacing, origin_pad, space_order, dt, src_coords, wavelet, rec_coords, npml, quibar=0.05,
+                dtype=np.float32, return_last=False):
+    """Shot record (nt, nrec) of the Grote-Sim scheme on the padded grid vp_pad (km/s); fields zero outside."""
+    t = np.dtype(dtype).type
+    vp = np.asarray(vp_pad, dtype=dtype)
+    n1, n2 = vp.shape
+    R = space_order // 2
+    w = fd2_weights(R)
+    hx, hz = float(spacing[0]), float(spacing[1])
+    c0 = t(w[0] / hx ** 2 + w[0] / hz ** 2)
+    cx = [t(w[k] / hx ** 2) for k in range(R + 1)]
+    cz = [t(w[k] / hz ** 2) for k in range(R + 1)]
+    m = (t(1) / (vp * vp)).astype(dtype)
+    zx0, zx1 = [a.astype(dtype) for a in pml_profiles(n1, npml, quibar)]
+    zz0, zz1 = [a.astype(dtype) for a in pml_profiles(n2, npml, quibar)]
+    ZX0, ZZ0 = zx0[:, None], zz0[None, :]
+    ZX1, ZZ1 = zx1[:, None], zz1[None, :]
+    # c^2 at the staggered points: mean of 1/m over the corners of the cell that lie inside the grid
+    inv = (t(1) / m).astype(dtype)
+    acc = inv.copy()
+    cnt = np.ones((n1, n2), dtype=dtype)
+    acc[:-1, :] += inv[1:, :]; cnt[:-1, :] += 1
+    acc[:, :-1] += inv[:, 1:]; cnt[:, :-1] += 1
+    acc[:-1, :-1] += inv[1:, 1:]; cnt[:-1, :-1] += 1
+    c2s = (acc / cnt).astype(dtype)
+    H = R + 1
+    def padz(a):
+        return np.pad(a, H)
+    sl = (slice(H, H + n1), slice(H, H + n2))
+    def sh(ap, dx, dz):
+        return ap[H + dx:H + dx + n1, H + dz:H + dz + n2]
+    nt = wavelet.shape[0]
+    wav = np.asarray(wavelet, dtype=dtype).reshape(nt, -1)
+    s_sup = _support_2d(src_coords, origin_pad, spacing, (n1, n2), dtype)
+    r_sup = _support_2d(rec_coords, origin_pad, spacing, (n1, n2), dtype)
+    rec = np.zeros((nt, len(r_sup)), dtype=dtype)
+    u = [np.zeros((n1, n2), dtype=dtype) for _ in range(3)]
+    p1 = [np.zeros((n1, n2), dtype=dtype) for _ in range(2)]
+    p2 = [np.zeros((n1, n2), dtype=dtype) for _ in range(2)]
+    dt_, dt2 = t(dt), t(dt) * t(dt)
+    half_s = (t(0.5) * (ZX0 + ZZ0) * dt_).astype(dtype)
+    layer = (ZX1 != 0) | (ZZ1 != 0)
+    for time in range(1, nt - 1):
+        cur, old, out = u[time % 3], u[(time + 2) % 3], u[(time + 1) % 3]
+        f1, f2 = padz(p1[time & 1]), padz(p2[time & 1])
+        cp = padz(cur)
+        lap = c0 * cur
+        for k in range(1, R + 1):
+            lap = lap + cz[k] * (sh(cp, 0, -k) + sh(cp, 0, k))
+        for k in range(1, R + 1):
+            lap = lap + cx[k] * (sh(cp, -k, 0) + sh(cp, k, 0))
+        P1 = -t(0.5 / hx) * (sh(f1, 0, -1) + sh(f1, 0, 0) - sh(f1, -1, -1) - sh(f1, -1, 0))
+        P2 = -t(0.5 / hz) * (sh(f2, -1, 0) + sh(f2, 0, 0) - sh(f2, -1, -1) - sh(f2, 0, -1))
+        rhs = t(2) * cur - old * (t(1) - half_s) + dt2 * (lap / m - ZX0 * ZZ0 * cur - P1 - P2)
+        out[...] = (rhs / (t(1) + half_s)).astype(dtype)
+        for p_, pts in enumerate(s_sup):                      # source into u[t+1] (cell 55)
+            for i, j, wgt in pts:
+                out[i, j] += wgt * wav[time, p_] * dt2 / m[i, j]
+        for p_, pts in enumerate(r_sup):                      # receivers sample u[t] (cell 56)
+            rec[time, p_] = sum((wgt * cur[i, j] for i, j, wgt in pts), t(0))
+        op, cq = padz(out), padz(cur)
+        a = (sh(op, 1, 0) + sh(op, 1, 1) - sh(op, 0, 0) - sh(op, 0, 1)) + (sh(cq, 1, 0) + sh(cq, 1, 1) - sh(cq, 0, 0) - sh(cq, 0, 1))
+        b = (sh(op, 0, 1) + sh(op, 1, 1) - sh(op, 0, 0) - sh(op, 1, 0)) + (sh(cq, 0, 1) + sh(cq, 1, 1) - sh(cq, 0, 0) - sh(cq, 1, 0))
+        idt = t(1) / dt_
+        n1_ = (p1[time & 1] * (idt - t(0.5) * ZX1) + (ZZ1 - ZX1) * c2s * t(0.25 / hx) * a) / (idt + t(0.5) * ZX1)
+        n2_ = (p2[time & 1] * (idt - t(0.5) * ZZ1) + (ZX1 - ZZ1) * c2s * t(0.25 / hz) * b) / (idt + t(0.5) * ZZ1)
+        p1[(time + 1) & 1][...] = np.where(layer, n1_, 0).astype(dtype)
+        p2[(time + 1) & 1][...] = np.where(layer, n2_, 0).astype(dtype)
+    if return_last:
+        return rec, np.stack([u[k] for k in range(3)])
+    return rec

@@ -1,0 +1,79 @@
+"""
+GPU parity of the perfectly matched layer option (MIFWI_FLAG_PML, mifwi_set_pml) against its CPU restatement
+(oracle.pml_forward, after seismic/abc_methods/03_pml.ipynb of the reference; parity unpinned: the reference
+holds no number for it).  Tolerances: rel-L2 2e-5 on shot records and wavefields in float32, 1e-11 in float64.
+"""
+import numpy as np
+import pytest
+
+from helpers import rel_l2, smooth_random_vp
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def _case(shape, npml, so, dtype, nshots=2, nrec=17, nt=260):
+    rng = np.random.default_rng(5)
+    vp = smooth_random_vp(tuple(s + 2 * npml for s in shape), vmin=1.5, vmax=3.0, seed=4).astype(dtype)
+    h = (10.0, 12.5)
+    origin = (-npml * h[0], -npml * h[1])
+    dt = 1.2
+    w = orc.ricker(0.02, dt * np.arange(nt)).reshape(nt, 1).astype(dtype)
+    dom = np.array([(shape[0] - 1) * h[0], (shape[1] - 1) * h[1]])
+    src = ((rng.random((nshots, 1, 2)) * 0.6 + 0.2) * dom).astype(dtype)
+    rec = (rng.random((nrec, 2)) * dom).astype(dtype)
+    return vp, h, origin, dt, w, src, rec
+
+
+@pytest.mark.parametrize("dtype,tol", [(np.float32, 2e-5), (np.float64, 1e-11)])
+@pytest.mark.parametrize("so", [2, 8])
+def test_pml_forward_parity(dtype, tol, so):
+    import mifwi
+    npml = 12
+    vp, h, origin, dt, w, src, rec = _case((50, 43), npml, so, dtype)
+    nt = w.shape[0]
+    plan = mifwi.Plan(vp.shape, h, origin, so, nt, dt, 1, rec.shape[0], max_shots=2, dtype=dtype, flags=mifwi.FLAG_PML)
+    plan.set_model(vp, np.zeros_like(vp))
+    plan.set_geometry(src, rec)
+    with pytest.raises(mifwi.MifwiError):
+        plan.forward(w)                       # mifwi_set_pml has not been called
+    plan.set_pml(npml, 0.05)
+    d = plan.forward(w)
+    for s in range(2):
+        ref, u_ref = orc.pml_forward(vp, h, origin, so, dt, src[s], w, rec, npml, dtype=dtype, return_last=True)
+        assert np.abs(ref).max() > 0
+        assert rel_l2(d[s], ref) <= tol, (s, rel_l2(d[s], ref))
+        assert rel_l2(plan.read_wavefield(1, shot=s), u_ref) <= tol
+    with pytest.raises(mifwi.MifwiError):
+        plan.forward(w, save=True)
+    with pytest.raises(mifwi.MifwiError):
+        plan.adjoint(d)
+    plan.close()
+    with pytest.raises(mifwi.MifwiError):
+        mifwi.Plan((20, 20, 20), (10.,) * 3, (0.,) * 3, 4, 10, 1.0, 1, 1, flags=mifwi.FLAG_PML)   # 2-D only
+
+
+def test_pml_through_the_solver_and_against_the_sponge():
+    """Model(bcs='pml') + AcousticWaveSolver.forward; at equal layer width the record is closer to that of a domain
+    without boundaries than the sponge's is (the reason to offer it)."""
+    from seismic import Model, AcquisitionGeometry
+    from seismic.acoustic import AcousticWaveSolver
+    n, nbl, so = 81, 20, 4
+    vp = np.full((n, n), 2.0, dtype=np.float32)
+    kw = dict(origin=(0., 0.), spacing=(10., 10.), shape=(n, n), space_order=so, vp=vp, dt=1.6)
+    rec_pos = np.stack([np.linspace(50.0, 750.0, 15), np.full(15, 120.0)], 1)
+    src_pos = np.array([[400.0, 400.0]])
+    out = {}
+    for bcs, pad in (("pml", nbl), ("damp", nbl), ("damp", 260)):
+        model = Model(nbl=pad, bcs=bcs, **kw)
+        geom = AcquisitionGeometry(model, rec_pos, src_pos, 0.0, 670.0, f0=0.02, src_type='Ricker')
+        solver = AcousticWaveSolver(model, geom, space_order=so)
+        rec, _, _ = solver.forward(vp=model.vp)
+        out[(bcs, pad)] = np.array(rec.data)
+        if bcs == "pml":
+            with pytest.raises(NotImplementedError):
+                solver.gradient(rec, None)
+    ref = out[("damp", 260)]                 # nothing comes back within the record
+    e_pml, e_sp = rel_l2(out[("pml", nbl)], ref), rel_l2(out[("damp", nbl)], ref)
+    print("record error against a domain without boundaries: layer %.3e, sponge %.3e" % (e_pml, e_sp))
+    assert e_pml < 0.02 and e_pml < e_sp

@@ -1,0 +1,69 @@
+"""
+The perfectly matched layer option: properties of the CPU restatement (oracle.pml_forward, which follows
+seismic/abc_methods/03_pml.ipynb of the reference).  The reference pins no number of the hot path with this
+boundary -- the notebook's last cell only bounds ||rec|| within a factor of two -- so the restatement is
+constrained by what the scheme must do: reduce to the plain propagator when the damping vanishes, absorb, and
+reproduce the record of a domain so large that nothing comes back.
+"""
+import numpy as np
+
+from oracle import oracle as orc
+
+
+def _setup(n=81, npml=20, so=4, nt=420, dtype=np.float64):
+    N = n + 2 * npml
+    vp = np.full((N, N), 2.0, dtype=dtype)
+    h = 10.0
+    origin = (-npml * h, -npml * h)
+    dt = 1.6
+    w = orc.ricker(0.02, dt * np.arange(nt)).reshape(nt, 1).astype(dtype)
+    src = np.array([[(n - 1) * h / 2, (n - 1) * h / 2]])
+    rec = np.stack([np.linspace(50.0, (n - 1) * h - 50.0, 15), np.full(15, 120.0)], 1)
+    return vp, (h, h), origin, so, dt, src, w, rec, npml, n
+
+
+def test_vanishing_damping_is_the_plain_propagator():
+    vp, sp, origin, so, dt, src, w, rec, npml, n = _setup(nt=200)
+    r = orc.pml_forward(vp, sp, origin, so, dt, src, w, rec, npml, quibar=0.0, dtype=np.float64)
+    prob = orc.Problem(vp[npml:-npml, npml:-npml], sp, npml, so, dtype=np.float64, dt=dt)
+    prob.damp[...] = 0
+    ref, _ = prob.forward(src, w, rec, dt=dt)
+    assert np.abs(ref).max() > 0
+    assert np.linalg.norm(r - ref) <= 1e-10 * np.linalg.norm(ref)
+
+
+def test_layer_absorbs_and_matches_a_domain_without_boundaries():
+    vp, sp, origin, so, dt, src, w, rec, npml, n = _setup()
+    r_pml, u_pml = orc.pml_forward(vp, sp, origin, so, dt, src, w, rec, npml, dtype=np.float64, return_last=True)
+    r_dir, u_dir = orc.pml_forward(vp, sp, origin, so, dt, src, w, rec, npml, quibar=0.0, dtype=np.float64,
+                                   return_last=True)
+    # the same acquisition in a domain so large that no reflection reaches the receivers in time
+    big = 260
+    vpb = np.full((n + 2 * big, n + 2 * big), 2.0)
+    r_inf = orc.pml_forward(vpb, sp, (-big * sp[0], -big * sp[1]), so, dt, src, w, rec, 1, quibar=0.0, dtype=np.float64)
+    err_pml = np.linalg.norm(r_pml - r_inf) / np.linalg.norm(r_inf)
+    err_dir = np.linalg.norm(r_dir - r_inf) / np.linalg.norm(r_inf)
+    print("record error against the unbounded domain: layer %.3e, no layer %.3e" % (err_pml, err_dir))
+    assert err_dir > 0.2            # reflections are strong without a layer ...
+    assert err_pml < 0.02           # ... and all but gone with it
+    # what is left in the physical domain at the end
+    phys = (slice(None), slice(npml, -npml), slice(npml, -npml))
+    e_pml, e_dir = np.linalg.norm(u_pml[phys]), np.linalg.norm(u_dir[phys])
+    print("field left in the physical domain: layer %.3e, no layer %.3e" % (e_pml, e_dir))
+    assert e_pml < 0.05 * e_dir
+    # the sponge of the same width (the parity path) for comparison: the layer must not be worse by much
+    prob = orc.Problem(vp[npml:-npml, npml:-npml], sp, npml, so, dtype=np.float64, dt=dt)
+    r_sp, _ = prob.forward(src, w, rec, dt=dt)
+    err_sp = np.linalg.norm(r_sp - r_inf) / np.linalg.norm(r_inf)
+    print("sponge of the same width: %.3e" % err_sp)
+    assert err_pml < 3 * err_sp
+
+
+def test_profiles_follow_the_notebook():
+    z0, z1 = orc.pml_profiles(141, 20)
+    assert z0[20] == 0 and z0[70] == 0 and z0[120] == 0
+    assert np.isclose(z0[0], 0.05) and np.isclose(z0[-1], 0.05)            # a = 1 at the outer edge
+    a = 0.5
+    assert np.isclose(z0[10], 0.05 * (a - np.sin(2 * np.pi * a) / (2 * np.pi)))
+    assert np.all(np.diff(z0[:21]) <= 0) and np.all(np.diff(z0[120:]) >= 0)
+    assert z1[19] > 0 and z1[20] == 0
