@@ -179,6 +179,11 @@ def roofline_3d(mifwi, device, space_order=16, n=512, nbl=40, nt=14):
     ach = 20.0 * ngrid / (best * 1e-3) / 1e9
     return {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
             "traffic": pmc_traffic("step3d_kernel"), "kernel": "step3d_kernel", "avg_launch_us": best * 1e3,
+            "profile_avg_launch_us": profile_launch_us("step3d_kernel"),
+            "gradient_step_profile": {"kernel": "step3d_kernel<GRAD>", "traffic": pmc_traffic("step3d_kernel<GRAD>"),
+                                      "profile_avg_launch_us": profile_launch_us("step3d_kernel<GRAD>"),
+                                      "what": "the launch of the space_order=8 gradient loop that advances the adjoint "
+                                              "field two steps' worth of gradient terms (config_3d_512)"},
             "gpoints_per_s": ngrid / (best * 1e-3) / 1e9,
             "workload": "synthetic 3-D %d^3 (+nbl %d = %d^3), space_order=%d, 1 shot, forward time step"
                         % (n, nbl, sp[0], space_order)}
@@ -515,6 +520,10 @@ def main():
                 if prof_us else None,
                 "profile": "profiles/r2_bench_kernel_stats.txt: rocprofv3 --kernel-trace of this command, mean over "
                            "the backward loop's launches (plain and two-step gradient launches weighted by count)",
+                "profile_note": "the tracer slows these ~5 us launches: HIP events around the same loop read 8.7 us "
+                                "per launch under rocprofv3 and 5.6 us without it (profiles/r2_bench_line_under_trace.json "
+                                "vs profiles/r2_bench_line_untraced.json), so the traced kernel-only mean exceeds the "
+                                "untraced launch-to-launch mean; the 0.9 ms 3-D launch agrees within 1 %",
                 "schedule": "the loop alternates a plain step (step2d_kernel mode 0) and a step that adds the "
                             "gradient terms of both (mode 4); launch time, bytes and traffic are means over the loop"}
     roofline_fwd = {"bound": "hbm", "achieved": f_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
