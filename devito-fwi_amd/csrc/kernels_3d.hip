@@ -70,6 +70,58 @@ __device__ inline void stv_stream(char *base, unsigned off, const float (&d)[V])
     for (int i = 0; i < V; ++i) v[i] = d[i];
     __builtin_nontemporal_store(v, reinterpret_cast<typename VecT<V>::type *>(base + off));
 }
+// The same accesses through a buffer descriptor: the instruction takes the descriptor and a plane offset from
+// scalar registers and a 32-bit byte offset per lane, so that no 64-bit address is formed per lane (flat
+// global addressing costs one 64-bit add and a register pair per access when the base moves with the loop).
+typedef int vi4 __attribute__((ext_vector_type(4)));
+__device__ vf4 raw_buffer_load_f4(vi4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.v4f32");
+__device__ vf2 raw_buffer_load_f2(vi4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.v2f32");
+__device__ void raw_buffer_store_f4(vf4 v, vi4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.store.v4f32");
+__device__ void raw_buffer_store_f2(vf2 v, vi4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.store.v2f32");
+// descriptor of the memory that starts at p (p is uniform over the block): no stride, no range check
+__device__ inline vi4 buf_of(const void *p)
+{
+    union {
+        struct {
+            const void *p;
+            unsigned n, f;
+        } s;
+        vi4 v;
+    } r;
+    r.s.p = p;
+    r.s.n = 0xffffffffu;
+    r.s.f = 0x00020000u;
+    return r.v;
+}
+constexpr int kBufStream = 2;   // non-temporal
+template <int V, int AUX = 0>
+__device__ inline void bldv(vi4 b, unsigned soff, unsigned off, float (&d)[V])
+{
+    if (V == 4) {
+        const vf4 v = raw_buffer_load_f4(b, (int)off, (int)soff, AUX);
+#pragma unroll
+        for (int i = 0; i < V; ++i) d[i] = v[i];
+    } else {
+        const vf2 v = raw_buffer_load_f2(b, (int)off, (int)soff, AUX);
+#pragma unroll
+        for (int i = 0; i < V; ++i) d[i] = v[i];
+    }
+}
+template <int V>
+__device__ inline void bstv_stream(vi4 b, unsigned soff, unsigned off, const float (&d)[V])
+{
+    if (V == 4) {
+        vf4 v;
+#pragma unroll
+        for (int i = 0; i < V; ++i) v[i] = d[i];
+        raw_buffer_store_f4(v, b, (int)off, (int)soff, kBufStream);
+    } else {
+        vf2 v;
+#pragma unroll
+        for (int i = 0; i < V; ++i) v[i] = d[i];
+        raw_buffer_store_f2(v, b, (int)off, (int)soff, kBufStream);
+    }
+}
 // V consecutive points of a half-precision saved level; `off` is their byte offset in a float field
 typedef unsigned vu2 __attribute__((ext_vector_type(2)));
 template <int V>
@@ -196,6 +248,9 @@ __global__ __launch_bounds__(TY *TZ / V, (MODE == 1 || MODE == 2 || MODE == 4 ? 
     char *out = reinterpret_cast<char *>(a.out + (long)shot * a.shot_stride);
     const char *mb = reinterpret_cast<const char *>(a.m);
     const char *eb = reinterpret_cast<const char *>(a.eta);
+    // descriptors: the stencilled level starts R planes early so that plane offsets are never negative
+    const unsigned sbu = (unsigned)sb;
+    const vi4 curB = buf_of(cur - (long)R * sb), oldB = buf_of(old), outB = buf_of(out), mB = buf_of(mb), eB = buf_of(eb);
 
     // halo-ring pieces (float4) of this thread: LDS offset and byte offset from a plane base
     int h_lds[NHT];
@@ -234,16 +289,16 @@ __global__ __launch_bounds__(TY *TZ / V, (MODE == 1 || MODE == 2 || MODE == 4 ? 
     for (int j = 0; j < 2 * R; ++j) {
 #pragma unroll
         for (int i = 0; i < V; ++i) q[j + 1][i] = 0.f;
-        if (live) ldv<V>(cur + (long)(xa - R + j) * sb, col, q[j + 1]);
+        if (live) bldv<V>(curB, (unsigned)(xa + j) * sbu, col, q[j + 1]);
     }
 #pragma unroll
     for (int i = 0; i < V; ++i) qn[i] = 0.f;
-    if (live) ldv<V>(cur + (long)(xa + R) * sb, col, qn);
+    if (live) bldv<V>(curB, (unsigned)(xa + 2 * R) * sbu, col, qn);
     float hv[NHT][4];
 #pragma unroll
     for (int i = 0; i < NHT; ++i) {
         hv[i][0] = hv[i][1] = hv[i][2] = hv[i][3] = 0.f;
-        if (h_ok[i]) ldv<4>(cur + (long)xa * sb, h_glb[i], hv[i]);
+        if (h_ok[i]) bldv<4>(curB, (unsigned)(xa + R) * sbu, h_glb[i], hv[i]);
     }
 
     float mm_n[V], ee_n[V], oo_n[V];
@@ -251,9 +306,9 @@ __global__ __launch_bounds__(TY *TZ / V, (MODE == 1 || MODE == 2 || MODE == 4 ? 
 #pragma unroll
         for (int i = 0; i < V; ++i) mm_n[i] = 1.f, ee_n[i] = 0.f, oo_n[i] = 0.f;
         if (live) {
-            ldv_stream<V>(mb + (long)xa * sb, col, mm_n);
-            if (!(ezero && ezero[xa] != 0)) ldv_stream<V>(eb + (long)xa * sb, col, ee_n);
-            ldv_stream<V>(old + (long)xa * sb, col, oo_n);
+            bldv<V, kBufStream>(mB, (unsigned)xa * sbu, col, mm_n);
+            if (!(ezero && ezero[xa] != 0)) bldv<V, kBufStream>(eB, (unsigned)xa * sbu, col, ee_n);
+            bldv<V, kBufStream>(oldB, (unsigned)xa * sbu, col, oo_n);
         }
     }
 
@@ -267,7 +322,7 @@ __global__ __launch_bounds__(TY *TZ / V, (MODE == 1 || MODE == 2 || MODE == 4 ? 
         }
 #pragma unroll
         for (int i = 0; i < V; ++i) q[2 * R][i] = qn[i];
-        if (live && x + 1 < xb) ldv<V>(cur + (long)(x + R + 1) * sb, col, qn);
+        if (live && x + 1 < xb) bldv<V>(curB, (unsigned)(x + 2 * R + 1) * sbu, col, qn);
         // this plane's coefficients are only needed once the stencil sum is complete
         float mm[V], ee[V], oo[V];
 #pragma unroll
@@ -278,9 +333,9 @@ __global__ __launch_bounds__(TY *TZ / V, (MODE == 1 || MODE == 2 || MODE == 4 ? 
 #pragma unroll
             for (int i = 0; i < V; ++i) mm[i] = mm_n[i], ee[i] = ee_n[i], oo[i] = oo_n[i];
         } else if (live) {
-            ldv_stream<V>(mb + (long)x * sb, col, mm);
-            if (!eta_is_zero) ldv_stream<V>(eb + (long)x * sb, col, ee);
-            ldv_stream<V>(old + (long)x * sb, col, oo);
+            bldv<V, kBufStream>(mB, (unsigned)x * sbu, col, mm);
+            if (!eta_is_zero) bldv<V, kBufStream>(eB, (unsigned)x * sbu, col, ee);
+            bldv<V, kBufStream>(oldB, (unsigned)x * sbu, col, oo);
         }
 
         // accumulators and saved level(s) of this plane: issued with the coefficient loads, used last
@@ -299,12 +354,14 @@ __global__ __launch_bounds__(TY *TZ / V, (MODE == 1 || MODE == 2 || MODE == 4 ? 
                     if (PAIR || (a.first && illumb))
                         ldv_half_stream<V>(reinterpret_cast<const char *>(a.up) + (us >> 1), col, inv, up);
                 } else {
-                    ldv_stream<V>(reinterpret_cast<const char *>(a.uc) + us, col, u0);
-                    if (PAIR || (a.first && illumb)) ldv_stream<V>(reinterpret_cast<const char *>(a.up) + us, col, up);
+                    const long ub = (long)shot * a.u_shot_stride * 4;
+                    bldv<V, kBufStream>(buf_of(reinterpret_cast<const char *>(a.uc) + ub), (unsigned)x * sbu, col, u0);
+                    if (PAIR || (a.first && illumb))
+                        bldv<V, kBufStream>(buf_of(reinterpret_cast<const char *>(a.up) + ub), (unsigned)x * sbu, col, up);
                 }
-                if (PAIR) ldv_stream<V>(out + (long)x * sb, col, po);   // backward level time + 2, about to be overwritten
-                ldv_stream<V>(gradb, col, g);
-                if (illumb) ldv_stream<V>(illumb, col, il);
+                if (PAIR) bldv<V, kBufStream>(outB, (unsigned)x * sbu, col, po);   // backward level time + 2, about to be overwritten
+                bldv<V, kBufStream>(buf_of(gradb - (long)x * sb), (unsigned)x * sbu, col, g);
+                if (illumb) bldv<V, kBufStream>(buf_of(illumb - (long)x * sb), (unsigned)x * sbu, col, il);
             }
         }
 
@@ -334,14 +391,14 @@ __global__ __launch_bounds__(TY *TZ / V, (MODE == 1 || MODE == 2 || MODE == 4 ? 
         if (x + 1 < xb) {
 #pragma unroll
             for (int i = 0; i < NHT; ++i)
-                if (h_ok[i]) ldv<4>(cur + (long)(x + 1) * sb, h_glb[i], hv[i]);
+                if (h_ok[i]) bldv<4>(curB, (unsigned)(x + 1 + R) * sbu, h_glb[i], hv[i]);
             if (PF) {
 #pragma unroll
                 for (int i = 0; i < V; ++i) ee_n[i] = 0.f;
                 if (live) {
-                    ldv_stream<V>(mb + (long)(x + 1) * sb, col, mm_n);
-                    if (!(ezero && ezero[x + 1] != 0)) ldv_stream<V>(eb + (long)(x + 1) * sb, col, ee_n);
-                    ldv_stream<V>(old + (long)(x + 1) * sb, col, oo_n);
+                    bldv<V, kBufStream>(mB, (unsigned)(x + 1) * sbu, col, mm_n);
+                    if (!(ezero && ezero[x + 1] != 0)) bldv<V, kBufStream>(eB, (unsigned)(x + 1) * sbu, col, ee_n);
+                    bldv<V, kBufStream>(oldB, (unsigned)(x + 1) * sbu, col, oo_n);
                 }
             }
         }
@@ -419,7 +476,7 @@ __global__ __launch_bounds__(TY *TZ / V, (MODE == 1 || MODE == 2 || MODE == 4 ? 
                 for (int i = 0; i < V; ++i) res[i] += acc[ty * TZ + V * tq + i];
             }
             if (full) {
-                stv_stream<V>(out + (long)x * sb, col, res);
+                bstv_stream<V>(outB, (unsigned)x * sbu, col, res);
             } else {
                 float *po = reinterpret_cast<float *>(out + (long)x * sb + col);
                 for (int i = 0; i < V; ++i)
@@ -466,8 +523,8 @@ __global__ __launch_bounds__(TY *TZ / V, (MODE == 1 || MODE == 2 || MODE == 4 ? 
                         il[i] = illum_accumulate(il[i], u0[i]);
                 }
                 if (full) {
-                    stv_stream<V>(gradb, col, g);
-                    if (illumb) stv_stream<V>(illumb, col, il);
+                    bstv_stream<V>(buf_of(gradb - (long)x * sb), (unsigned)x * sbu, col, g);
+                    if (illumb) bstv_stream<V>(buf_of(illumb - (long)x * sb), (unsigned)x * sbu, col, il);
                 } else {
                     float *pg = reinterpret_cast<float *>(gradb + col);
                     float *pi = illumb ? reinterpret_cast<float *>(illumb + col) : nullptr;
