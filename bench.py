@@ -300,7 +300,8 @@ def fwi_iteration(true_model, init_model, src_all, rec, k=3, reps=3):
     mask[:, :15] = 0
     m0 = 1.0 / np.asarray(init_model.vp.data[init_model.nbl:-init_model.nbl,
                                              init_model.nbl:-init_model.nbl], dtype=np.float64).reshape(-1) ** 2
-    fwi_loss(m0, g_init, obs, least_square, None, mask, True)                       # warm-up
+    fwi_loss(m0, g_init, obs, least_square, None, mask, True)                       # warm-up of both kinds of call
+    fwi_loss(m0, g_init, obs, least_square, None, mask, True, calc_grad=False)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for r in range(reps):

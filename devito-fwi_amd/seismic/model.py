@@ -6,6 +6,8 @@ acoustic case (isotropic or TTI) with numpy arrays in place of Devito functions;
 drivers and `AcousticWaveSolver` touch is present with the same meaning (reference file:line
 given per member).  Elastic / visco parameters are outside this package's scope and raise.
 """
+import functools
+
 import numpy as np
 
 from .fields import Grid, Function, Constant
@@ -13,8 +15,10 @@ from .fields import Grid, Function, Constant
 __all__ = ['SeismicModel', 'Model', 'GenericModel', 'initialize_damp']
 
 
+@functools.lru_cache(maxsize=None)
 def _second_derivative_weights(radius):
-    """Centred 2nd-derivative FD weights on -radius..radius, index 0 = centre (closed form)."""
+    """Centred 2nd-derivative FD weights on -radius..radius, index 0 = centre (closed form).
+    The array is shared between callers: read only."""
     w = np.zeros(radius + 1)
     for k in range(1, radius + 1):
         q = 1.0
@@ -22,6 +26,7 @@ def _second_derivative_weights(radius):
             q *= (radius - k + j) / float(radius + j)
         w[k] = (2.0 if k % 2 else -2.0) * q / (k * k)
     w[0] = -2.0 * w[1:].sum()
+    w.setflags(write=False)
     return w
 
 
