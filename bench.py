@@ -527,11 +527,32 @@ def main():
                                 "untraced launch-to-launch mean; the 0.9 ms 3-D launch agrees within 1 %",
                 "schedule": "the loop alternates a plain step (step2d_kernel mode 0) and a step that adds the "
                             "gradient terms of both (mode 4); launch time, bytes and traffic are means over the loop"}
+    whole_loop = st["bwd_kernel"].startswith("persist2d")
+    if whole_loop:
+        # One launch runs the whole backward loop with the model, the two newest levels and the gradient sums of a
+        # tile resident in registers / LDS: per point and step it still has to read the saved forward level (4 B),
+        # write the new level for its neighbours (4 B) and read the halo ring (ring / tile = 1.25 -> 5 B).
+        moved = 13.0 * ngrid * per_gpu * steps_per_loop
+        roofline.update({
+            "timing": "HIP events around the backward time loop on the plan's stream (one launch runs the whole loop)",
+            "schedule": "one launch per loop: every tile keeps a block resident and synchronises with its neighbours "
+                        "through per-tile counters in the L2 of the XCD that holds the shot",
+            "steps_per_launch": steps_per_loop, "us_per_step": bwd_ms * 1e3 / steps_per_loop,
+            "bytes_this_kernel_moves": {"per_point_and_step": 13.0, "achieved": moved / (bwd_ms * 1e-3) / 1e9,
+                                        "frac": moved / (bwd_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                        "what": "saved forward level read + new level written + halo ring read; "
+                                                "`achieved` and `frac` above price the step at the 32 B per point "
+                                                "that a kernel per step has to move"},
+            "bound_note": "the loop is bound by the neighbour synchronisation of each step (1.6 us per step for the "
+                          "exchange alone, tools/micro/xcdsync.hip), not by HBM"})
+        roofline.pop("profile_note", None)
     roofline_fwd = {"bound": "hbm", "achieved": f_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": f_ach / HBM_PEAK_GBS, "traffic": pmc_traffic(st["fwd_kernel"]), "kernel": st["fwd_kernel"],
                     "launches_per_loop": fwd_launches, "avg_launch_us": fwd_ms * 1e3 / max(1, fwd_launches),
                     "profile_avg_launch_us": profile_launch_us(st["fwd_kernel"])}
 
+    if st["fwd_kernel"].startswith("persist2d"):
+        roofline_fwd.update({"steps_per_launch": steps_per_loop, "us_per_step": fwd_ms * 1e3 / steps_per_loop})
     out = {
         "metric": "Gpoints/s (fwd+adj), Marmousi-II, %s" % ("%d-shot survey sharded over the GPUs" % nshots_total if strong
                                                            else "8 shots per GPU"),

@@ -1,0 +1,435 @@
+// Whole time loops of small 2-D batches in ONE launch (float32, 32 x 32 tiles, at most one shot per XCD).
+//
+// A time step of a Marmousi-sized batch moves a few megabytes; launched as one kernel per step it costs
+// what a dependent kernel boundary plus one load -> LDS -> store round trip costs, not what its bytes
+// cost.  Here every tile of a shot keeps a block resident for the whole loop:
+//   * the block holds m, eta and its own points of the two newest levels in registers (and, in the
+//     gradient variant, its points of the gradient and illumination sums), so per step it reads only the
+//     halo ring of the newest level (written by its neighbours) and one saved forward level, and writes its
+//     tile of the new level (plus the saved copy in a saving forward loop);
+//   * neighbours synchronise through one counter per tile: a block publishes "step s done" after its
+//     stores have reached the L2, and waits for its eight neighbours' counters before it reads their
+//     halos.  All tiles of a shot run on ONE XCD -- each block reads the XCC id of the hardware it landed
+//     on and takes the next free tile of the shot dealt to that XCD -- so the L2 they share is the
+//     point of coherence: the counter is stored with group scope, counters and halos are read with loads
+//     that miss the per-CU L1, and no cache is flushed or invalidated.  Measured cost of the exchange
+//     alone on MI355X: 1.6 us per step against 4.3 us for a kernel per step.
+//   * every wait is bounded.  A block that waits too long raises the abort flag and every block leaves;
+//     the host then repeats the loop with one kernel per step.  Nothing depends on how the hardware deals
+//     blocks to XCDs except speed: an uneven deal only makes the abort path run.
+// Arithmetic, sparse terms and summation orders are those of step2d_kernel (kernels_tiled2d.hip).
+#include "mifwi_internal.hpp"
+
+namespace mifwi {
+
+typedef int vi4 __attribute__((ext_vector_type(4)));
+typedef float vf4 __attribute__((ext_vector_type(4)));
+__device__ vf4 raw_buffer_load_f4(vi4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.v4f32");
+__device__ int raw_buffer_load_i1(vi4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.i32");
+__device__ void raw_buffer_store_f4(vf4 v, vi4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.store.v4f32");
+__device__ inline vi4 buf_of(const void *p)
+{
+    union {
+        struct {
+            const void *p;
+            unsigned n, f;
+        } s;
+        vi4 v;
+    } r;
+    r.s.p = p;
+    r.s.n = 0xffffffffu;
+    r.s.f = 0x00020000u;
+    return r.v;
+}
+constexpr int kPlain = 0, kStream = 2 /* non-temporal */, kMissL1 = 16 /* device scope: misses the per-CU L1, served by the L2 */;
+
+__device__ inline float fast_div_r(float a, float b, float r)
+{
+    // a / b with r = refined reciprocal of b (see fast_div in kernels_tiled2d.hip): same result, the
+    // reciprocal is formed once per loop because b = m + eta dt does not change
+    const float q = a * r;
+    return __builtin_fmaf(__builtin_fmaf(-b, q, a), r, q);
+}
+__device__ inline float refined_rcp(float b)
+{
+    float r = __builtin_amdgcn_rcpf(b);
+    return __builtin_fmaf(__builtin_fmaf(-b, r, 1.0f), r, r);
+}
+
+// MODE 0: propagation (forward or backward in time), 1: backward with gradient and illumination sums
+template <int R, int MODE>
+__global__ __launch_bounds__(256, 4) void persist2d_kernel(Persist2DArgs q)
+{
+    constexpr bool GRAD = (MODE == 1);
+    constexpr int TX = 32, TZ = 32, V = 4, NT = 256;
+    constexpr int RZ = (R + 3) / 4 * 4, RZ4 = RZ / 4;
+    constexpr int ROWF4 = (TZ + 2 * RZ) / 4;
+    constexpr int P = tile2d_lds_pitch(TZ, R);
+    constexpr int TQ = TZ / V;
+    constexpr int NBAND = R * ROWF4;             // float4 in the band above (below) the tile
+    constexpr int NH = 2 * NBAND + 2 * TX * RZ4; // float4 in the halo ring
+    constexpr int NHT = (NH + NT - 1) / NT;
+    __shared__ __attribute__((aligned(16))) float lds[(TX + 2 * R) * P];
+    __shared__ __attribute__((aligned(16))) float acc[TX * TZ];
+    __shared__ int s_list[NT];
+    __shared__ short s_own_off[4][NT];   // staged-tile offsets of the four corners of the point a thread samples
+    __shared__ float s_own_w[4][NT];
+    // gradient and illumination sums of a thread's points: one private slot per thread (no register is free
+    // for them at four blocks per CU)
+    __shared__ __attribute__((aligned(16))) float s_sums[GRAD ? 2 * V * NT : 4];
+    __shared__ int s_misc[4];
+
+    const Step2DArgs &a = q.a;
+    const int tid = threadIdx.x;
+    if (tid == 0) {
+        const int xcc = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 15;   // XCC_ID, bits 3:0
+        s_misc[0] = xcc;
+        s_misc[1] = atomicAdd(&q.counter[xcc], 1);
+        s_misc[2] = 0;
+    }
+    __syncthreads();
+    // this launch advances shots shot0 .. shot0 + nshots - 1 (at most 8), one per XCD
+    const int group_slot = s_misc[0], tile = s_misc[1];
+    const int ntiles = a.ntx * a.ntz;
+    if (group_slot >= a.nshots || tile >= ntiles) return;   // block-uniform: nothing to do on this XCD / surplus block
+    const int shot = a.shot0 + group_slot;
+
+    const int tile_x = tile / a.ntz, tile_z = tile - tile_x * a.ntz;
+    const int x0 = tile_x * TX, z0 = tile_z * TZ;
+    const int tx = tid / TQ, tq = tid - tx * TQ;
+    const int x = x0 + tx, z = z0 + V * tq;
+    const bool live = (x < a.n1) && (z < a.n2);
+    const bool full = (z + V - 1 < a.n2);
+    const unsigned pb = ((unsigned)a.off0 + (unsigned)x * (unsigned)a.s1 + (unsigned)z) * 4u;
+    const unsigned lvl_bytes = (unsigned)q.field * 4u;
+    float *rot = q.rot + (long)shot * 3 * q.field;
+    const vi4 rotB = buf_of(rot);
+
+    // eight neighbours: lanes 0..7 of the block watch one counter each
+    int nbr = -1;
+    if (tid < 8) {
+        const int k = tid < 4 ? tid : tid + 1;   // skip the centre of the 3 x 3 neighbourhood
+        const int nx = tile_x + k / 3 - 1, nz = tile_z + k % 3 - 1;
+        if (nx >= 0 && nx < a.ntx && nz >= 0 && nz < a.ntz) nbr = nx * a.ntz + nz;
+    }
+    int *done = q.done + group_slot * ntiles;
+    const vi4 doneB = buf_of(done), abortB = buf_of(q.abort_flag);
+
+    // halo-ring pieces (float4) of this thread
+    int h_lds[NHT];
+    unsigned h_glb[NHT];
+    bool h_ok[NHT];
+#pragma unroll
+    for (int i = 0; i < NHT; ++i) {
+        const int h = tid + i * NT;
+        int row, c4;
+        if (h < 2 * NBAND) {
+            const int band = h / NBAND, r = (h - band * NBAND) / ROWF4;
+            c4 = h - band * NBAND - r * ROWF4;
+            row = band ? (R + TX + r) : r;
+        } else {
+            const int hh = h - 2 * NBAND;
+            const int r = hh / (2 * RZ4), cc = hh - r * (2 * RZ4);
+            row = R + r;
+            c4 = cc < RZ4 ? cc : (TZ / 4 + cc);
+        }
+        const int gx = x0 - R + row;
+        h_ok[i] = (h < NH) && (gx < a.n1 + R);
+        h_lds[i] = row * P + 4 * c4;
+        h_glb[i] = (unsigned)((int)a.off0 + gx * (int)a.s1 + (z0 - RZ + 4 * c4)) * 4u;
+    }
+
+    // sampled points whose first corner with a weight lies in this tile: at most one per thread
+    // (the host checks the capacity before choosing this kernel)
+    int own_id = -1;
+    if (a.pt_idx) {
+        const int tab = a.itp_per_shot ? shot : 0;
+        for (int pnt = tid; pnt < a.itp_npoint; pnt += NT) {
+            const int4 idx = *reinterpret_cast<const int4 *>(a.pt_idx + ((long)tab * a.itp_npoint + pnt) * 4);
+            const float4 w = *reinterpret_cast<const float4 *>(a.pt_w + ((long)tab * a.itp_npoint + pnt) * 4);
+            const int first = w.x != 0.f ? idx.x : w.y != 0.f ? idx.y : w.z != 0.f ? idx.z : w.w != 0.f ? idx.w : -1;
+            if (first < 0) continue;
+            const int rel = first - (int)a.off0;
+            const int gx = rel / (int)a.s1, gz = rel - gx * (int)a.s1;
+            if (gx / TX == tile_x && gz / TZ == tile_z) {
+                const int k = atomicAdd(&s_misc[2], 1);
+                if (k < NT) s_list[k] = pnt;
+            }
+        }
+        __syncthreads();
+        if (tid < s_misc[2] && tid < NT) {
+            own_id = s_list[tid];
+            const int4 idx = *reinterpret_cast<const int4 *>(a.pt_idx + ((long)tab * a.itp_npoint + own_id) * 4);
+            const float4 w = *reinterpret_cast<const float4 *>(a.pt_w + ((long)tab * a.itp_npoint + own_id) * 4);
+            const int ii[4] = {idx.x, idx.y, idx.z, idx.w};
+            const float ww[4] = {w.x, w.y, w.z, w.w};
+            int own_off[4], fallback = 0;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int rel = ii[c] - (int)a.off0;
+                const int gx = rel / (int)a.s1, gz = rel - gx * (int)a.s1;
+                own_off[c] = (gx - x0 + R) * P + (gz - z0 + RZ);
+                if (ww[c] != 0.f && fallback == 0) fallback = own_off[c];
+            }
+            // corners without weight point anywhere inside the staged tile
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                s_own_off[c][tid] = (short)(ww[c] == 0.f ? fallback : own_off[c]);
+                s_own_w[c][tid] = ww[c];
+            }
+        }
+    }
+
+    const int inj_tab = a.inj_per_shot ? shot : 0;
+    const long tslot = (long)inj_tab * ntiles + tile;
+    const int ninj = a.slot_count ? a.slot_count[tslot] : 0;   // block-uniform
+    const int inj_base = ninj > 0 ? a.slot_base[tslot] : 0;
+    const int wj_cell = (ninj > 0 && tid < ninj) ? a.slot_local[tslot * a.inj_cap + tid] : -1;   // the cell this thread feeds
+
+    // state kept in registers for the whole loop
+    const int time0 = q.forward ? 1 : a.nt - 2;
+    const int dir = q.forward ? 1 : -1;
+    float mm[V], ed[V], ucur[V], uold[V];
+#pragma unroll
+    for (int i = 0; i < V; ++i) mm[i] = 1.f, ed[i] = 0.f, ucur[i] = 0.f, uold[i] = 0.f;
+    vf4 *const sum_g = reinterpret_cast<vf4 *>(s_sums) + tid, *const sum_il = reinterpret_cast<vf4 *>(s_sums) + (GRAD ? NT : 0) + tid;
+    if (GRAD) *sum_g = vf4{0.f, 0.f, 0.f, 0.f}, *sum_il = vf4{0.f, 0.f, 0.f, 0.f};
+    const char *usv = GRAD ? reinterpret_cast<const char *>(q.usaved + (long)shot * q.field) : nullptr;
+    const long usv_l = q.usaved_lstride * 4;   // bytes between saved levels
+    if (live) {
+        const float4 m4 = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(a.m) + pb);
+        const float4 e4 = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(a.eta) + pb);
+        const float4 c4 = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(rot) + (long)(time0 % 3) * lvl_bytes + pb);
+        const float4 o4 = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(rot) + (long)((time0 - dir + 3) % 3) * lvl_bytes + pb);
+        mm[0] = m4.x, mm[1] = m4.y, mm[2] = m4.z, mm[3] = m4.w;
+        ed[0] = e4.x * a.dt, ed[1] = e4.y * a.dt, ed[2] = e4.z * a.dt, ed[3] = e4.w * a.dt;
+        ucur[0] = c4.x, ucur[1] = c4.y, ucur[2] = c4.z, ucur[3] = c4.w;
+        uold[0] = o4.x, uold[1] = o4.y, uold[2] = o4.z, uold[3] = o4.w;
+        if (GRAD) {
+            const float4 g4 = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(a.grad + (long)shot * a.g_shot_stride) + pb);
+            *sum_g = vf4{g4.x, g4.y, g4.z, g4.w};
+            if (a.illum) {
+                float il[V];
+                const float4 i4 = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(a.illum + (long)shot * a.g_shot_stride) + pb);
+                il[0] = i4.x, il[1] = i4.y, il[2] = i4.z, il[3] = i4.w;
+                // the level after the first one enters the illumination once, with the first step
+                const float4 p4 = *reinterpret_cast<const float4 *>(usv + (long)(time0 + 1) * usv_l + pb);
+                const float pp[4] = {p4.x, p4.y, p4.z, p4.w};
+#pragma unroll
+                for (int i = 0; i < V; ++i) il[i] = illum_accumulate(il[i], pp[i]);
+                *sum_il = vf4{il[0], il[1], il[2], il[3]};
+            }
+        }
+    }
+
+    for (int s = 0; s < q.nsteps; ++s) {
+        const int time = time0 + dir * s;
+        const unsigned cur_off = (unsigned)(time % 3) * lvl_bytes;
+        const unsigned out_off = (unsigned)((time + dir + 3) % 3) * lvl_bytes;
+
+        // loads that depend on nothing this step produces: injected terms, the next saved level
+        float wj = 0.f;
+        if (wj_cell >= 0) wj = a.winj[((long)shot * a.nt + time) * a.winj_stride + inj_base + tid];
+        // the saved forward level of this step is needed last: its load has the whole step to arrive
+        vf4 u0 = vf4{0.f, 0.f, 0.f, 0.f};
+        if (GRAD && live) u0 = raw_buffer_load_f4(buf_of(usv + (long)time * usv_l), (int)pb, 0, kStream);
+        // own points of the newest level: from registers
+        *reinterpret_cast<vf4 *>(&lds[(tx + R) * P + RZ + V * tq]) = vf4{ucur[0], ucur[1], ucur[2], ucur[3]};
+        if (ninj > 0) {
+#pragma unroll
+            for (int i = 0; i < V; ++i) acc[V * tid + i] = 0.f;
+        }
+
+        // wait until the neighbours have published the level this step reads
+        int fail = 0;
+        if (s > 0 && nbr >= 0) {
+            int n = 0;
+            while (raw_buffer_load_i1(doneB, nbr * 4, 0, kMissL1) < s) {
+                if (++n > q.spin_limit || ((n & 255) == 0 && raw_buffer_load_i1(abortB, 0, 0, kMissL1) != 0)) {
+                    fail = 1;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(1);
+            }
+        }
+        fail = __syncthreads_or(fail);   // also orders the zeroing of acc before its scatter
+        if (fail) {
+            if (tid == 0) __hip_atomic_store(q.abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return;
+        }
+        vf4 hv[NHT];
+#pragma unroll
+        for (int i = 0; i < NHT; ++i) {
+            hv[i] = vf4{0.f, 0.f, 0.f, 0.f};
+            if (h_ok[i]) hv[i] = raw_buffer_load_f4(rotB, (int)h_glb[i], (int)cur_off, kMissL1);
+        }
+        if (ninj > 0) {
+            if (wj_cell >= 0) acc[wj_cell] = wj;
+            for (int j = tid + NT; j < ninj; j += NT)   // more owned cells than threads (rare)
+                acc[a.slot_local[tslot * a.inj_cap + j]] = a.winj[((long)shot * a.nt + time) * a.winj_stride + inj_base + j];
+        }
+#pragma unroll
+        for (int i = 0; i < NHT; ++i)
+            if (tid + i * NT < NH) *reinterpret_cast<vf4 *>(&lds[h_lds[i]]) = hv[i];
+        __syncthreads();
+
+        // sampled points of the level being read
+        if (own_id >= 0) {
+            const float sum = s_own_w[0][tid] * lds[s_own_off[0][tid]] + s_own_w[1][tid] * lds[s_own_off[1][tid]] +
+                              s_own_w[2][tid] * lds[s_own_off[2][tid]] + s_own_w[3][tid] * lds[s_own_off[3][tid]];
+            a.vals_out[((long)shot * a.nt + time) * a.itp_npoint + own_id] = sum;
+        }
+
+        float res[V];
+#pragma unroll
+        for (int i = 0; i < V; ++i) res[i] = 0.f;
+        if (live) {
+            const float *ctr = &lds[(tx + R) * P + RZ + V * tq];
+            float f[V + 2 * RZ];
+#pragma unroll
+            for (int k = 0; k < (V + 2 * RZ) / V; ++k) {
+                const vf4 t = *reinterpret_cast<const vf4 *>(ctr - RZ + V * k);
+#pragma unroll
+                for (int i = 0; i < V; ++i) f[V * k + i] = t[i];
+            }
+            float lap[V], uc[V];
+#pragma unroll
+            for (int i = 0; i < V; ++i) {
+                uc[i] = ucur[i];   // what this thread staged, f[RZ + i]
+                lap[i] = a.c0 * uc[i];
+            }
+#pragma unroll
+            for (int k = 1; k <= R; ++k) {
+#pragma unroll
+                for (int i = 0; i < V; ++i) lap[i] += a.cz[k] * (f[RZ + i - k] + f[RZ + i + k]);
+            }
+#pragma unroll
+            for (int k = 1; k <= R; ++k) {
+                const vf4 lo = *reinterpret_cast<const vf4 *>(ctr - k * P);
+                const vf4 hi = *reinterpret_cast<const vf4 *>(ctr + k * P);
+#pragma unroll
+                for (int i = 0; i < V; ++i) lap[i] += a.cx[k] * (lo[i] + hi[i]);
+            }
+#pragma unroll
+            for (int i = 0; i < V; ++i)
+                res[i] = fast_div_r(a.dt2 * lap[i] + 2.0f * mm[i] * uc[i] - mm[i] * uold[i] + ed[i] * uc[i], mm[i] + ed[i],
+                                    refined_rcp(mm[i] + ed[i]));
+            if (ninj > 0) {
+#pragma unroll
+                for (int i = 0; i < V; ++i) res[i] += acc[V * tid + i];
+            }
+            if (!full) {
+                // points past the end of a row are halo: they stay zero in the registers as they do in memory
+#pragma unroll
+                for (int i = 0; i < V; ++i)
+                    if (z + i >= a.n2) res[i] = 0.f;
+            }
+            if (full) {
+                raw_buffer_store_f4(vf4{res[0], res[1], res[2], res[3]}, rotB, (int)pb, (int)out_off, kPlain);
+            } else {
+                float *po = reinterpret_cast<float *>(reinterpret_cast<char *>(rot) + out_off + pb);
+                for (int i = 0; i < V; ++i)
+                    if (z + i < a.n2) po[i] = res[i];
+            }
+            if (q.saved) {
+                // the saved forward levels are write-only streams here
+                float *sp = q.saved + (long)(time + 1) * q.saved_lstride + (long)shot * q.field;
+                if (full) {
+                    raw_buffer_store_f4(vf4{res[0], res[1], res[2], res[3]}, buf_of(sp), (int)pb, 0, kStream);
+                } else {
+                    float *pp = reinterpret_cast<float *>(reinterpret_cast<char *>(sp) + pb);
+                    for (int i = 0; i < V; ++i)
+                        if (z + i < a.n2) pp[i] = res[i];
+                }
+            }
+            if (GRAD) {
+                vf4 g = *sum_g, il = *sum_il;
+#pragma unroll
+                for (int i = 0; i < V; ++i) {
+                    g[i] = grad_accumulate(g[i], uold[i], uc[i], res[i], u0[i], a.inv_dt2);
+                    il[i] = illum_accumulate(il[i], u0[i]);
+                }
+                *sum_g = g, *sum_il = il;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < V; ++i) uold[i] = ucur[i], ucur[i] = res[i];
+
+        // publish: this wave's stores have reached the L2, then every wave's, then the counter moves
+        __builtin_amdgcn_s_waitcnt(0);
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store(&done[tile], s + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+
+    if (GRAD && live) {
+        float *gp = reinterpret_cast<float *>(reinterpret_cast<char *>(a.grad + (long)shot * a.g_shot_stride) + pb);
+        float *ip = a.illum ? reinterpret_cast<float *>(reinterpret_cast<char *>(a.illum + (long)shot * a.g_shot_stride) + pb) : nullptr;
+        const vf4 g = *sum_g, il = *sum_il;
+        for (int i = 0; i < V; ++i)
+            if (z + i < a.n2) {
+                gp[i] = g[i];
+                if (ip) ip[i] = il[i];
+            }
+    }
+}
+
+template <int R>
+static int occupancy_persist(bool grad)
+{
+    int nb = 0;
+    hipError_t e = grad ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, persist2d_kernel<R, 1>, 256, 0)
+                        : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, persist2d_kernel<R, 0>, 256, 0);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return nb;
+}
+
+// resident blocks per CU of the persistent kernel for this radius (0: not available)
+int persist2d_blocks_per_cu(int R, bool grad)
+{
+    switch (R) {
+        case 1: return occupancy_persist<1>(grad);
+        case 2: return occupancy_persist<2>(grad);
+        case 3: return occupancy_persist<3>(grad);
+        case 4: return occupancy_persist<4>(grad);
+        case 5: return occupancy_persist<5>(grad);
+        case 6: return occupancy_persist<6>(grad);
+        case 7: return occupancy_persist<7>(grad);
+        case 8: return occupancy_persist<8>(grad);
+    }
+    return 0;
+}
+
+template <int R>
+static int launch_pr(const Persist2DArgs &q, bool grad, int nblocks, hipStream_t stream)
+{
+    if (grad)
+        hipLaunchKernelGGL((persist2d_kernel<R, 1>), dim3(nblocks), dim3(256), 0, stream, q);
+    else
+        hipLaunchKernelGGL((persist2d_kernel<R, 0>), dim3(nblocks), dim3(256), 0, stream, q);
+    MIFWI_HIP(hipGetLastError());
+    return MIFWI_OK;
+}
+
+// One launch = the whole time loop.  blocks_per_xcd blocks are dealt to each of the 8 XCDs (ids modulo 8);
+// those beyond the tiles of a shot leave at once.
+int launch_persist2d(const Plan &p, const Persist2DArgs &q, bool grad, int blocks_per_xcd, hipStream_t stream)
+{
+    const int nblocks = 8 * blocks_per_xcd;
+    switch (p.L.R) {
+        case 1: return launch_pr<1>(q, grad, nblocks, stream);
+        case 2: return launch_pr<2>(q, grad, nblocks, stream);
+        case 3: return launch_pr<3>(q, grad, nblocks, stream);
+        case 4: return launch_pr<4>(q, grad, nblocks, stream);
+        case 5: return launch_pr<5>(q, grad, nblocks, stream);
+        case 6: return launch_pr<6>(q, grad, nblocks, stream);
+        case 7: return launch_pr<7>(q, grad, nblocks, stream);
+        case 8: return launch_pr<8>(q, grad, nblocks, stream);
+    }
+    set_error("unsupported stencil radius");
+    return MIFWI_EINVAL;
+}
+
+}  // namespace mifwi

@@ -168,6 +168,8 @@ static void destroy(Plan *p)
     dev_free(p->pml_zeta);
     dev_free(p->d_winj[0]);
     dev_free(p->d_winj[1]);
+    dev_free(p->d_psync);
+    if (p->h_abort) (void)hipHostFree(p->h_abort);
     dev_free(p->tti_par);
     dev_free(p->tti_fwd);
     dev_free(p->tti_adj);
@@ -365,6 +367,17 @@ static int build_sparse(Plan &p, SparseSet &S, const T *coords /* [tables][npoin
                 }
         }
         if (ntiles) {
+            // points sampled per tile, a point counted for the tile of its first corner that carries a weight
+            std::vector<int> own(ntiles, 0);
+            for (int q = 0; q < npoint; ++q)
+                for (int b = 0; b < nc; ++b) {
+                    const size_t e = ((size_t)t * npoint + q) * nc + b;
+                    if (pt_w[e] == T(0)) continue;
+                    const long rel = (long)pt_idx[e] - L.off0;
+                    const int i1 = (int)(rel / L.s1), i2 = (int)(rel % L.s1);
+                    S.max_own = std::max(S.max_own, ++own[(i1 / p.tile_tx) * p.ntz + (i2 / p.tile_tz)]);
+                    break;
+                }
             auto &tt = tiles[t];
             tt.resize(ntiles);
             tile_u[t].resize(ntiles);
@@ -508,6 +521,9 @@ static int create(const mifwi_config *cfg, mifwi_plan **out)
         if (const char *env = getenv("MIFWI_2D_TX")) p->tile_tx = atoi(env), p->tile_tz = 32;  // tuning experiments
         p->ntx = (n1 + p->tile_tx - 1) / p->tile_tx;
         p->ntz = (n2 + p->tile_tz - 1) / p->tile_tz;
+        hipDeviceProp_t prop{};
+        if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) p->ncu = prop.multiProcessorCount;
+        if (const char *env = getenv("MIFWI_PERSIST")) p->persist = atoi(env);   // 0: one kernel per step always
     }
     if (cfg->ndim == 3 && cfg->dtype == MIFWI_F32 && !(cfg->flags & (MIFWI_FLAG_GENERIC | MIFWI_FLAG_OT4))) {
         // 2.5-D fast path: 16 x 64 tiles of the (y, z) plane, x split into chunks so that one launch
@@ -652,7 +668,8 @@ static void fill_stats(Plan &p, double ms, double steps, int nshots, double byte
     p.stats.gpointss = ms > 0 ? p.stats.points / (ms * 1e-3) / 1e9 : 0.0;
     p.stats.algorithmic_bytes = p.stats.points * bytes_per_point * (p.esize / 4.0);
     p.stats.launches = launches;
-    p.stats.kernel_kind = p.kind;
+    p.stats.kernel_kind = p.loop_persist ? 3 : p.kind;
+    p.loop_persist = false;
     p.stats.device_bytes = p.device_bytes;
     p.stats.ckpt_steps = p.ck_K > 0 ? p.ck_nc : 0;
     p.stats.ckpt_segment = p.ck_K;
@@ -1181,6 +1198,76 @@ static int prepare_save(Plan &p)
 }
 
 // forward time loop on data already resident on the device (d_wavelet -> d_rec)
+// ---- whole time loops in one launch (kernels_persist2d.hip) ---------------------------------------
+// `sampled`: the point set the loop interpolates (its points must fit one per thread and tile), or null.
+static bool persist_eligible(Plan &p, int nshots, const SparseSet *sampled, bool grad)
+{
+    if (!p.persist || p.kind != 1 || p.esize != 4 || p.save_f16) return false;
+    if (p.cfg.flags & (MIFWI_FLAG_ASYNC | MIFWI_FLAG_NO_GRAPH | MIFWI_FLAG_FREE_SURFACE)) return false;
+    if (p.tile_tx != 32 || p.tile_tz != 32 || p.vec2d != 4) return false;
+    if (p.cfg.nt < 3) return false;
+    if ((unsigned long long)p.L.field * 12ull >= (1ull << 31)) return false;   // a shot's three levels behind one descriptor
+    if (sampled && sampled->max_own > 256) return false;
+    int &bpc = p.persist_bpc[grad ? 1 : 0];
+    if (bpc < 0) bpc = persist2d_blocks_per_cu(p.L.R, grad);
+    // every tile of a shot needs a resident block on the shot's XCD for the whole loop
+    return bpc * (p.ncu / 8) >= p.ntx * p.ntz;
+}
+
+// Queue the launches that run the whole loop -- one per group of 8 shots (one shot per XCD), one group after
+// the other -- and the read-back of the abort flag.
+static int enqueue_persist(Plan &p, int nshots, bool forward, bool with_grad, bool with_illum, bool save, int &launches)
+{
+    const Layout &L = p.L;
+    const int ntiles = p.ntx * p.ntz;
+    const size_t nsync = (size_t)8 * ntiles + 16 + 4;
+    int rc;
+    if (!p.d_psync) {
+        if ((rc = dev_alloc(p, (void **)&p.d_psync, nsync * sizeof(int), true))) return rc;
+        MIFWI_HIP(hipHostMalloc((void **)&p.h_abort, sizeof(int), hipHostMallocDefault));
+    }
+    MIFWI_HIP(hipMemsetAsync(p.d_psync, 0, nsync * sizeof(int), p.stream));
+    const size_t ngroup_words = (size_t)8 * ntiles + 16;   // counters a launch uses; the abort flag after them is shared
+    Persist2DArgs q{};
+    q.a = base2d(p, nshots);
+    if (forward) {
+        set_inject(q.a, p.src, p);
+        set_interp(q.a, p.rec, p.d_rec);
+        q.rot = (float *)p.rot_u;
+    } else {
+        set_inject(q.a, p.rec, p);
+        if (!with_grad) set_interp(q.a, p.src, p.d_srca);
+        q.rot = (float *)p.rot_v;
+    }
+    if (with_grad) {
+        q.a.grad = (float *)p.d_grad;
+        q.a.illum = with_illum ? (float *)p.d_illum : nullptr;
+        q.a.g_shot_stride = L.field;
+        q.usaved = (const float *)p.saved;
+        q.usaved_lstride = (long)p.cfg.max_shots * L.field;
+    }
+    q.field = L.field;
+    q.forward = forward ? 1 : 0;
+    q.nsteps = p.cfg.nt - 2;
+    q.saved = (forward && save) ? (float *)p.saved : nullptr;
+    q.saved_lstride = (long)p.cfg.max_shots * L.field;
+    q.done = p.d_psync;
+    q.counter = p.d_psync + 8 * ntiles;
+    q.abort_flag = q.counter + 16;
+    q.spin_limit = 1 << 21;
+    const int resident = p.persist_bpc[with_grad ? 1 : 0] * (p.ncu / 8);
+    launches = 0;
+    for (int s0 = 0; s0 < nshots; s0 += 8) {
+        if (s0 > 0) MIFWI_HIP(hipMemsetAsync(p.d_psync, 0, ngroup_words * sizeof(int), p.stream));
+        q.a.shot0 = s0;
+        q.a.nshots = std::min(8, nshots - s0);
+        if ((rc = launch_persist2d(p, q, with_grad, std::min(resident, ntiles + 16), p.stream))) return rc;
+        launches += 1;
+    }
+    MIFWI_HIP(hipMemcpyAsync(p.h_abort, q.abort_flag, sizeof(int), hipMemcpyDeviceToHost, p.stream));
+    return MIFWI_OK;
+}
+
 template <typename T>
 static int run_forward(Plan &p, int nshots, int save)
 {
@@ -1303,7 +1390,17 @@ static int run_forward(Plan &p, int nshots, int save)
     int launches = 0;
     float ms = 0;
     const auto key = std::make_tuple(0, nshots, save ? 1 : 0, slab_w, 0);
-    if ((rc = timed_loop(p, ckpt ? nullptr : &key, enqueue, launches, ms))) return rc;
+    if (!ckpt && !in_saved && persist_eligible(p, nshots, &p.rec, false)) {
+        auto whole_loop = [&](int &n) -> int { return enqueue_persist(p, nshots, true, false, false, copy_save, n); };
+        if ((rc = timed_loop(p, nullptr, whole_loop, launches, ms))) return rc;
+        if (*p.h_abort) {   // a block waited too long for a neighbour: never again on this plan, and this loop anew
+            p.persist = 0;
+            return run_forward<T>(p, nshots, save);
+        }
+        p.loop_persist = true;
+    } else if ((rc = timed_loop(p, ckpt ? nullptr : &key, enqueue, launches, ms))) {
+        return rc;
+    }
     fill_stats(p, ms, nt - 2, nshots, 20.0, launches, false);
     if (save) {
         p.saved_valid = true;
@@ -1426,7 +1523,17 @@ static int run_backward(Plan &p, int nshots, bool with_grad, bool with_illum)
     int launches = 0;
     float ms = 0;
     const auto key = std::make_tuple(1, nshots, with_grad ? 1 : 0, with_illum ? 1 : 0, 0);
-    if ((rc = timed_loop(p, ckpt ? nullptr : &key, enqueue, launches, ms, true))) return rc;
+    if (!ckpt && persist_eligible(p, nshots, with_grad ? nullptr : &p.src, with_grad)) {
+        auto whole_loop = [&](int &n) -> int { return enqueue_persist(p, nshots, false, with_grad, with_illum, false, n); };
+        if ((rc = timed_loop(p, nullptr, whole_loop, launches, ms, true))) return rc;
+        if (*p.h_abort) {
+            p.persist = 0;
+            return run_backward<T>(p, nshots, with_grad, with_illum);
+        }
+        p.loop_persist = true;
+    } else if ((rc = timed_loop(p, ckpt ? nullptr : &key, enqueue, launches, ms, true))) {
+        return rc;
+    }
     fill_stats(p, ms, nt - 2, nshots, with_grad ? 32.0 : 20.0, launches, true);
     p.rot_v_valid = true;
     return MIFWI_OK;

@@ -84,6 +84,7 @@ struct SparseSet {
     void *slot_ew = nullptr;       // [tables][ntiles][cap][maxe] weight (0 when padding)
     int32_t *slot_base = nullptr;  // [tables][ntiles] first position of the tile's cells in tile-major order
     int32_t *g_u = nullptr;        // [tables][kmax] unique-cell index (into uc_*) of tile-major position g
+    int max_own = 0;               // most points any tile samples (a point belongs to the tile of its first weighted corner)
     // Injection view of the 2.5-D kernel: owned cells ordered by ((y,z) tile, x plane)
     int32_t *cell_ptr = nullptr;   // [tables][ntiles][n0+1] ranges into cell_local / cell_uc
     int32_t *cell_local = nullptr; // [tables][kmax] tile-local (y,z) index of the cell
@@ -175,6 +176,12 @@ struct Plan {
     int vec2d = 4;      // points per thread of the tiled 2-D kernel (2: experiment, 32 x 32 tiles only)
     int pair_save = 1;  // saving forward loops of the tiled 2-D kernel write two saved levels every second step
     int pair_grad = 1;  // gradient loops update the accumulators every second step (tiled kernels)
+    // whole-loop launches of the tiled 2-D kernel's work (kernels_persist2d.hip)
+    int persist = 1;                   // 0: never (MIFWI_PERSIST=0, or a loop had to be abandoned once)
+    int persist_bpc[2] = {-1, -1};     // resident blocks per CU of the plain / gradient variant, -1 = not asked yet
+    int *d_psync = nullptr;            // per-tile step counters [8][tiles], blocks taken per XCD [16], abort flag
+    int *h_abort = nullptr;            // pinned host copy of the abort flag
+    bool loop_persist = false;         // the loop whose statistics are being filled in ran that way
 
     // captured time loops: (loop kind, nshots, variant a, variant b, group) -> executable graph + launches
     std::map<std::tuple<int, int, int, int, int>, std::pair<hipGraphExec_t, int>> graphs;
@@ -404,6 +411,25 @@ struct Step2DArgs {
     long b_shot_stride;
 };
 int launch_step2d(const Plan &p, const Step2DArgs &a, hipStream_t stream);
+
+// ---- whole time loops of small 2-D batches in one launch (kernels_persist2d.hip) ----------------
+struct Persist2DArgs {
+    Step2DArgs a;          // constants, model, injection and interpolation tables, gradient sums (cur/old/out/time unused)
+    float *rot;            // [shots][3][field] rotating levels of the field being advanced; level t lives in slot t % 3
+    long field;
+    int forward;           // 1: time runs 1 .. nt-2, 0: nt-2 .. 1
+    int nsteps;
+    float *saved;          // forward loops: every new level is also streamed to saved[time + 1][shot], or null
+    long saved_lstride;    // elements between saved levels
+    const float *usaved;   // gradient loops: the saved forward field
+    long usaved_lstride;
+    int *done;             // [8][tiles] steps completed by each tile
+    int *counter;          // [16] blocks that have taken a tile, per XCD
+    int *abort_flag;
+    int spin_limit;        // polls of a neighbour's counter before the loop is abandoned
+};
+int persist2d_blocks_per_cu(int R, bool grad);
+int launch_persist2d(const Plan &p, const Persist2DArgs &q, bool grad, int blocks_per_xcd, hipStream_t stream);
 
 // ---- 2.5-D fast path for 3-D grids (kernels_3d.hip) -------------------------------------------
 struct Step3DArgs {

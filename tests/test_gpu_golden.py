@@ -90,4 +90,14 @@ def test_marmousi2_golden_shot_inside_a_batch(batch, pos):
     assert np.array_equal(one["illum"][0], out["illum"][pos])
     assert one["fval"][0] == out["fval"][pos]
     single.close()
+    # and a kernel per step instead of a launch per loop gives the same numbers
+    steps = mifwi.Plan(m_true.grid.shape, c["spacing"], m_true.grid.origin, so, nt, dt, 1, g["rec"].shape[0],
+                       flags=mifwi.FLAG_NO_GRAPH)
+    steps.set_geometry(src[pos:pos + 1], g["rec"])
+    steps.set_model(m_init.vp.data, m_init.damp.data)
+    two = steps.l2_misfit_gradient(w, obs[pos:pos + 1], want_illum=True)
+    assert rel_l2(two["grad"][0], one["grad"][0]) < 5e-5
+    assert rel_l2(two["illum"][0], one["illum"][0]) < 5e-6
+    assert np.isclose(two["fval"][0], one["fval"][0], rtol=1e-6)
+    steps.close()
     plan.close()
