@@ -57,11 +57,12 @@ __device__ inline float refined_rcp(float b)
 }
 
 // MODE 0: propagation (forward or backward in time), 1: backward with gradient and illumination sums
-template <int R, int MODE>
+template <int R, int TX, int TZ, int MODE>
 __global__ __launch_bounds__(256, 4) void persist2d_kernel(Persist2DArgs q)
 {
     constexpr bool GRAD = (MODE == 1);
-    constexpr int TX = 32, TZ = 32, V = 4, NT = 256;
+    constexpr int V = 4, NT = TX * TZ / V;
+    static_assert(NT == 256, "tiles of 1024 points");
     constexpr int RZ = (R + 3) / 4 * 4, RZ4 = RZ / 4;
     constexpr int ROWF4 = (TZ + 2 * RZ) / 4;
     constexpr int P = tile2d_lds_pitch(TZ, R);
@@ -273,12 +274,11 @@ __global__ __launch_bounds__(256, 4) void persist2d_kernel(Persist2DArgs q)
             if (tid + i * NT < NH) *reinterpret_cast<vf4 *>(&lds[h_lds[i]]) = hv[i];
         __syncthreads();
 
-        // sampled points of the level being read
-        if (own_id >= 0) {
-            const float sum = s_own_w[0][tid] * lds[s_own_off[0][tid]] + s_own_w[1][tid] * lds[s_own_off[1][tid]] +
-                              s_own_w[2][tid] * lds[s_own_off[2][tid]] + s_own_w[3][tid] * lds[s_own_off[3][tid]];
-            a.vals_out[((long)shot * a.nt + time) * a.itp_npoint + own_id] = sum;
-        }
+        // sampled points of the level being read (stored after this step's level has been published)
+        float sampled = 0.f;
+        if (own_id >= 0)
+            sampled = s_own_w[0][tid] * lds[s_own_off[0][tid]] + s_own_w[1][tid] * lds[s_own_off[1][tid]] +
+                      s_own_w[2][tid] * lds[s_own_off[2][tid]] + s_own_w[3][tid] * lds[s_own_off[3][tid]];
 
         float res[V];
 #pragma unroll
@@ -331,17 +331,6 @@ __global__ __launch_bounds__(256, 4) void persist2d_kernel(Persist2DArgs q)
                 for (int i = 0; i < V; ++i)
                     if (z + i < a.n2) po[i] = res[i];
             }
-            if (q.saved) {
-                // the saved forward levels are write-only streams here
-                float *sp = q.saved + (long)(time + 1) * q.saved_lstride + (long)shot * q.field;
-                if (full) {
-                    raw_buffer_store_f4(vf4{res[0], res[1], res[2], res[3]}, buf_of(sp), (int)pb, 0, kStream);
-                } else {
-                    float *pp = reinterpret_cast<float *>(reinterpret_cast<char *>(sp) + pb);
-                    for (int i = 0; i < V; ++i)
-                        if (z + i < a.n2) pp[i] = res[i];
-                }
-            }
             if (GRAD) {
                 vf4 g = *sum_g, il = *sum_il;
 #pragma unroll
@@ -359,6 +348,19 @@ __global__ __launch_bounds__(256, 4) void persist2d_kernel(Persist2DArgs q)
         __builtin_amdgcn_s_waitcnt(0);
         __syncthreads();
         if (tid == 0) __hip_atomic_store(&done[tile], s + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+
+        // write-only streams nobody waits for: they drain while the next step waits for its neighbours
+        if (own_id >= 0) a.vals_out[((long)shot * a.nt + time) * a.itp_npoint + own_id] = sampled;
+        if (q.saved && live) {
+            float *sp = q.saved + (long)(time + 1) * q.saved_lstride + (long)shot * q.field;
+            if (full) {
+                raw_buffer_store_f4(vf4{ucur[0], ucur[1], ucur[2], ucur[3]}, buf_of(sp), (int)pb, 0, kStream);
+            } else {
+                float *pp = reinterpret_cast<float *>(reinterpret_cast<char *>(sp) + pb);
+                for (int i = 0; i < V; ++i)
+                    if (z + i < a.n2) pp[i] = ucur[i];
+            }
+        }
     }
 
     if (GRAD && live) {
@@ -373,44 +375,55 @@ __global__ __launch_bounds__(256, 4) void persist2d_kernel(Persist2DArgs q)
     }
 }
 
-template <int R>
-static int occupancy_persist(bool grad)
+template <int R, int TX, int TZ>
+static int occupancy_persist_t(bool grad)
 {
     int nb = 0;
-    hipError_t e = grad ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, persist2d_kernel<R, 1>, 256, 0)
-                        : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, persist2d_kernel<R, 0>, 256, 0);
+    hipError_t e = grad ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, persist2d_kernel<R, TX, TZ, 1>, 256, 0)
+                        : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, persist2d_kernel<R, TX, TZ, 0>, 256, 0);
     if (e != hipSuccess) {
         (void)hipGetLastError();
         return 0;
     }
     return nb;
 }
+template <int R>
+static int occupancy_persist(bool grad, int tile_tz)
+{
+    return tile_tz == 64 ? occupancy_persist_t<R, 16, 64>(grad) : occupancy_persist_t<R, 32, 32>(grad);
+}
 
-// resident blocks per CU of the persistent kernel for this radius (0: not available)
-int persist2d_blocks_per_cu(int R, bool grad)
+// resident blocks per CU of the persistent kernel for this radius and tile shape (32 x 32 or 16 x 64); 0: not available
+int persist2d_blocks_per_cu(int R, int tile_tz, bool grad)
 {
     switch (R) {
-        case 1: return occupancy_persist<1>(grad);
-        case 2: return occupancy_persist<2>(grad);
-        case 3: return occupancy_persist<3>(grad);
-        case 4: return occupancy_persist<4>(grad);
-        case 5: return occupancy_persist<5>(grad);
-        case 6: return occupancy_persist<6>(grad);
-        case 7: return occupancy_persist<7>(grad);
-        case 8: return occupancy_persist<8>(grad);
+        case 1: return occupancy_persist<1>(grad, tile_tz);
+        case 2: return occupancy_persist<2>(grad, tile_tz);
+        case 3: return occupancy_persist<3>(grad, tile_tz);
+        case 4: return occupancy_persist<4>(grad, tile_tz);
+        case 5: return occupancy_persist<5>(grad, tile_tz);
+        case 6: return occupancy_persist<6>(grad, tile_tz);
+        case 7: return occupancy_persist<7>(grad, tile_tz);
+        case 8: return occupancy_persist<8>(grad, tile_tz);
     }
     return 0;
 }
 
-template <int R>
-static int launch_pr(const Persist2DArgs &q, bool grad, int nblocks, hipStream_t stream)
+template <int R, int TX, int TZ>
+static int launch_prt(const Persist2DArgs &q, bool grad, int nblocks, hipStream_t stream)
 {
     if (grad)
-        hipLaunchKernelGGL((persist2d_kernel<R, 1>), dim3(nblocks), dim3(256), 0, stream, q);
+        hipLaunchKernelGGL((persist2d_kernel<R, TX, TZ, 1>), dim3(nblocks), dim3(256), 0, stream, q);
     else
-        hipLaunchKernelGGL((persist2d_kernel<R, 0>), dim3(nblocks), dim3(256), 0, stream, q);
+        hipLaunchKernelGGL((persist2d_kernel<R, TX, TZ, 0>), dim3(nblocks), dim3(256), 0, stream, q);
     MIFWI_HIP(hipGetLastError());
     return MIFWI_OK;
+}
+template <int R>
+static int launch_pr(const Plan &p, const Persist2DArgs &q, bool grad, int nblocks, hipStream_t stream)
+{
+    if (p.tile_tz == 64) return launch_prt<R, 16, 64>(q, grad, nblocks, stream);
+    return launch_prt<R, 32, 32>(q, grad, nblocks, stream);
 }
 
 // One launch = the whole time loop.  blocks_per_xcd blocks are dealt to each of the 8 XCDs (ids modulo 8);
@@ -419,14 +432,14 @@ int launch_persist2d(const Plan &p, const Persist2DArgs &q, bool grad, int block
 {
     const int nblocks = 8 * blocks_per_xcd;
     switch (p.L.R) {
-        case 1: return launch_pr<1>(q, grad, nblocks, stream);
-        case 2: return launch_pr<2>(q, grad, nblocks, stream);
-        case 3: return launch_pr<3>(q, grad, nblocks, stream);
-        case 4: return launch_pr<4>(q, grad, nblocks, stream);
-        case 5: return launch_pr<5>(q, grad, nblocks, stream);
-        case 6: return launch_pr<6>(q, grad, nblocks, stream);
-        case 7: return launch_pr<7>(q, grad, nblocks, stream);
-        case 8: return launch_pr<8>(q, grad, nblocks, stream);
+        case 1: return launch_pr<1>(p, q, grad, nblocks, stream);
+        case 2: return launch_pr<2>(p, q, grad, nblocks, stream);
+        case 3: return launch_pr<3>(p, q, grad, nblocks, stream);
+        case 4: return launch_pr<4>(p, q, grad, nblocks, stream);
+        case 5: return launch_pr<5>(p, q, grad, nblocks, stream);
+        case 6: return launch_pr<6>(p, q, grad, nblocks, stream);
+        case 7: return launch_pr<7>(p, q, grad, nblocks, stream);
+        case 8: return launch_pr<8>(p, q, grad, nblocks, stream);
     }
     set_error("unsupported stencil radius");
     return MIFWI_EINVAL;

@@ -524,6 +524,7 @@ static int create(const mifwi_config *cfg, mifwi_plan **out)
         hipDeviceProp_t prop{};
         if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) p->ncu = prop.multiProcessorCount;
         if (const char *env = getenv("MIFWI_PERSIST")) p->persist = atoi(env);   // 0: one kernel per step always
+        if (const char *env = getenv("MIFWI_PERSIST_SPIN")) p->persist_spin = atoi(env);   // tests: 0 abandons at once
     }
     if (cfg->ndim == 3 && cfg->dtype == MIFWI_F32 && !(cfg->flags & (MIFWI_FLAG_GENERIC | MIFWI_FLAG_OT4))) {
         // 2.5-D fast path: 16 x 64 tiles of the (y, z) plane, x split into chunks so that one launch
@@ -1204,12 +1205,12 @@ static bool persist_eligible(Plan &p, int nshots, const SparseSet *sampled, bool
 {
     if (!p.persist || p.kind != 1 || p.esize != 4 || p.save_f16) return false;
     if (p.cfg.flags & (MIFWI_FLAG_ASYNC | MIFWI_FLAG_NO_GRAPH | MIFWI_FLAG_FREE_SURFACE)) return false;
-    if (p.tile_tx != 32 || p.tile_tz != 32 || p.vec2d != 4) return false;
+    if (!((p.tile_tx == 32 && p.tile_tz == 32) || (p.tile_tx == 16 && p.tile_tz == 64)) || p.vec2d != 4) return false;
     if (p.cfg.nt < 3) return false;
     if ((unsigned long long)p.L.field * 12ull >= (1ull << 31)) return false;   // a shot's three levels behind one descriptor
     if (sampled && sampled->max_own > 256) return false;
     int &bpc = p.persist_bpc[grad ? 1 : 0];
-    if (bpc < 0) bpc = persist2d_blocks_per_cu(p.L.R, grad);
+    if (bpc < 0) bpc = persist2d_blocks_per_cu(p.L.R, p.tile_tz, grad);
     // every tile of a shot needs a resident block on the shot's XCD for the whole loop
     return bpc * (p.ncu / 8) >= p.ntx * p.ntz;
 }
@@ -1254,7 +1255,7 @@ static int enqueue_persist(Plan &p, int nshots, bool forward, bool with_grad, bo
     q.done = p.d_psync;
     q.counter = p.d_psync + 8 * ntiles;
     q.abort_flag = q.counter + 16;
-    q.spin_limit = 1 << 21;
+    q.spin_limit = p.persist_spin;
     const int resident = p.persist_bpc[with_grad ? 1 : 0] * (p.ncu / 8);
     launches = 0;
     for (int s0 = 0; s0 < nshots; s0 += 8) {

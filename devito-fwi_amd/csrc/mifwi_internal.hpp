@@ -178,6 +178,7 @@ struct Plan {
     int pair_grad = 1;  // gradient loops update the accumulators every second step (tiled kernels)
     // whole-loop launches of the tiled 2-D kernel's work (kernels_persist2d.hip)
     int persist = 1;                   // 0: never (MIFWI_PERSIST=0, or a loop had to be abandoned once)
+    int persist_spin = 1 << 21;        // polls of a neighbour's counter before a loop is abandoned (MIFWI_PERSIST_SPIN)
     int persist_bpc[2] = {-1, -1};     // resident blocks per CU of the plain / gradient variant, -1 = not asked yet
     int *d_psync = nullptr;            // per-tile step counters [8][tiles], blocks taken per XCD [16], abort flag
     int *h_abort = nullptr;            // pinned host copy of the abort flag
@@ -428,7 +429,7 @@ struct Persist2DArgs {
     int *abort_flag;
     int spin_limit;        // polls of a neighbour's counter before the loop is abandoned
 };
-int persist2d_blocks_per_cu(int R, bool grad);
+int persist2d_blocks_per_cu(int R, int tile_tz, bool grad);
 int launch_persist2d(const Plan &p, const Persist2DArgs &q, bool grad, int blocks_per_xcd, hipStream_t stream);
 
 // ---- 2.5-D fast path for 3-D grids (kernels_3d.hip) -------------------------------------------

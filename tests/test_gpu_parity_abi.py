@@ -126,10 +126,12 @@ def test_error_paths(mifwi):
 
 
 @pytest.mark.parametrize("kind", ["2d", "3d", "2d-generic"])
-def test_checkpointed_gradient_is_bit_identical(mifwi, kind):
+def test_checkpointed_gradient_is_bit_identical(mifwi, kind, monkeypatch):
     """Two-level checkpointing (segments recomputed before the backward pass crosses them) must give
     exactly the gradient of the fully saved wavefield -- the 'blocked == unblocked' equivalence of
-    the reference's tutorials/12_time_blocking.ipynb, here bit for bit."""
+    the reference's tutorials/12_time_blocking.ipynb, here bit for bit (both with a kernel per step: a
+    checkpointed loop is never run as one launch)."""
+    monkeypatch.setenv("MIFWI_PERSIST", "0")
     if kind == "3d":
         case = Case((20, 18, 22), (10.0, 10.0, 10.0), nbl=6, space_order=8, nt=97, nshots=2, nrec=12, seed=21)
         flags = 0
@@ -221,10 +223,11 @@ def test_no_receivers_and_no_sources(mifwi):
     plan.close()
 
 
-def test_user_stream_async_and_device_buffers(mifwi):
+def test_user_stream_async_and_device_buffers(mifwi, monkeypatch):
     """mifwi_set_stream + MIFWI_FLAG_ASYNC with inputs and outputs that live on the GPU (torch tensors):
-    same numbers as the synchronous host-buffer calls."""
+    same numbers as the synchronous host-buffer calls (run with a kernel per step, as asynchronous plans do)."""
     import torch
+    monkeypatch.setenv("MIFWI_PERSIST", "0")
     case = Case((45, 38), (10.0, 12.5), nbl=9, space_order=8, nt=120, nshots=2, nrec=13, seed=4)
     ref_plan = case.plan(mifwi)
     rec_ref = ref_plan.forward(case.wavelet, save=True)

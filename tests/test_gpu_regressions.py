@@ -20,10 +20,11 @@ def mifwi():
     return m
 
 
-def test_async_calls_return_before_the_work_is_done(mifwi):
+def test_async_calls_return_before_the_work_is_done(mifwi, monkeypatch):
     """MIFWI_FLAG_ASYNC: a propagation call only enqueues its time loop.  The host returns long before the
     GPU has finished, two plans can be kept busy from one thread, and times and results are there after
-    mifwi_synchronize / mifwi_get_stats."""
+    mifwi_synchronize / mifwi_get_stats.  (The synchronous reference runs a kernel per step too.)"""
+    monkeypatch.setenv("MIFWI_PERSIST", "0")
     case = Case((300, 260), (10.0, 10.0), nbl=20, space_order=8, nt=4000, nshots=4, nrec=50, seed=2)
     ref = case.plan(mifwi)
     ref.forward(case.wavelet)            # first run: graph capture, cold clocks

@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
+#include <algorithm>
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
 
 typedef int vi4 __attribute__((ext_vector_type(4)));
@@ -127,13 +128,79 @@ __global__ __launch_bounds__(256) void k_persist(Args a)
     if (bad) atomicAdd(a.mismatch, bad);
 }
 
+
+// Mailbox variant: no counters.  A block writes, for each of its four neighbours, a strip of 16-byte chunks
+// (three payload floats + the step number) into that neighbour's mailbox of the step's parity, and a reader polls
+// the chunks themselves until they carry the step it wants: one round trip instead of counter + data, and the
+// writer never waits for its stores.  CHUNKS chunks per edge.
+constexpr int CHUNKS = 86;
+__device__ void raw_buffer_store_f4(vf4 v, vi4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.store.v4f32");
+__global__ __launch_bounds__(256) void k_mailbox(Args a)
+{
+    __shared__ int s_slot, s_xcc;
+    const int tid = threadIdx.x;
+    if (tid == 0) {
+        const int xcc = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20);
+        s_xcc = xcc;
+        s_slot = atomicAdd(&a.counter[xcc], 1);
+        atomicAdd(&a.xcc_seen[xcc], 1);
+    }
+    __syncthreads();
+    const int shot = s_xcc, tile = s_slot;
+    if (shot >= a.nshots || tile >= NTILE) return;
+    const int tx = tile / NTZ, tz = tile % NTZ;
+    const int nb[4] = {tx > 0 ? tile - NTZ : -1, tx < NTX - 1 ? tile + NTZ : -1, tz > 0 ? tile - 1 : -1, tz < NTZ - 1 ? tile + 1 : -1};
+    // mailbox of (shot, tile, edge e, parity p): CHUNKS float4; edge e of a tile is written by neighbour nb[e]
+    // through that neighbour's opposite edge (e ^ 1)
+    float *box = a.buf + (long)shot * NTILE * 4 * 2 * CHUNKS * 4;
+    const vi4 boxB = buf_of(box);
+    auto box_off = [&](int t, int e, int par, int c) { return ((((t * 4 + e) * 2 + par) * CHUNKS) + c) * 16; };
+    // each thread handles chunks tid and tid + 256 of the 4 * CHUNKS incoming ones
+    int bad = 0;
+    for (int t = 1; t <= a.nsteps; ++t) {
+        // write own strips for step t (payload encodes writer and step)
+        for (int c = tid; c < 4 * CHUNKS; c += 256) {
+            const int e = c / CHUNKS, cc = c - e * CHUNKS;
+            if (nb[e] < 0) continue;
+            raw_buffer_store_f4(vf4{tile * 4096.f + t, (float)cc, 0.f, __int_as_float(t)}, boxB, box_off(nb[e], e ^ 1, t & 1, cc), 0, 0);
+        }
+        // read the strips the neighbours wrote for step t
+        int fail = 0;
+        for (int c = tid; c < 4 * CHUNKS; c += 256) {
+            const int e = c / CHUNKS, cc = c - e * CHUNKS;
+            if (nb[e] < 0) continue;
+            int n = 0;
+            vf4 v;
+            while (true) {
+                v = raw_buffer_load_f4(boxB, box_off(tile, e, t & 1, cc), 0, 16);
+                if (__float_as_int(v.w) == t) break;
+                if (++n > SPIN_LIMIT || ((n & 63) == 0 && __hip_atomic_load(a.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+                    fail = 1;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            if (!fail && (v.x != nb[e] * 4096.f + t || v.y != (float)cc)) ++bad;
+        }
+        fail = __syncthreads_or(fail);
+        if (fail) {
+            if (tid == 0) __hip_atomic_store(a.abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return;
+        }
+        __syncthreads();   // stands for the barrier after staging the halo in LDS
+        if (tid == 0) a.done[shot * NTILE + tile] = t;
+    }
+    if (bad) atomicAdd(a.mismatch, bad);
+}
+
 int main(int argc, char **argv)
 {
     const int nsteps = argc > 1 ? atoi(argv[1]) : 2000, nshots = argc > 2 ? atoi(argv[2]) : 8, mode = argc > 3 ? atoi(argv[3]) : 0;
     Args a;
     a.nsteps = nsteps, a.nshots = nshots, a.mode = mode;
-    CK(hipMalloc(&a.buf, sizeof(float) * 2 * nshots * NTILE * TPTS));
-    CK(hipMemset(a.buf, 0, sizeof(float) * 2 * nshots * NTILE * TPTS));
+    const size_t nbuf = std::max((size_t)2 * nshots * NTILE * TPTS, (size_t)nshots * NTILE * 4 * 2 * CHUNKS * 4);
+    CK(hipMalloc(&a.buf, sizeof(float) * nbuf));
+    CK(hipMemset(a.buf, 0, sizeof(float) * nbuf));
     int *flags;
     const int nflag = nshots * NTILE + 16 + 1 + 1 + 16;
     CK(hipMalloc(&flags, sizeof(int) * nflag));
@@ -146,8 +213,12 @@ int main(int argc, char **argv)
     const int per_xcd = 112, nblocks = 8 * per_xcd;
     for (int rep = 0; rep < 3; ++rep) {
         CK(hipMemset(flags, 0, sizeof(int) * nflag));
+        CK(hipMemset(a.buf, 0, sizeof(float) * nbuf));
         CK(hipEventRecord(e0));
-        hipLaunchKernelGGL(k_persist, dim3(nblocks), dim3(256), 0, 0, a);
+        if (mode == 1000)
+            hipLaunchKernelGGL(k_mailbox, dim3(nblocks), dim3(256), 0, 0, a);
+        else
+            hipLaunchKernelGGL(k_persist, dim3(nblocks), dim3(256), 0, 0, a);
         CK(hipEventRecord(e1));
         CK(hipEventSynchronize(e1));
         float ms;
