@@ -519,11 +519,11 @@ def main():
                 "profile_avg_launch_us": prof_us,
                 "profile_frac": (g_bytes_loop / max(1, bwd_launches)) / (prof_us * 1e-6) / 1e9 / HBM_PEAK_GBS
                 if prof_us else None,
-                "profile": "profiles/r2_bench_kernel_stats.txt: rocprofv3 --kernel-trace of this command, mean over "
+                "profile": "profiles/r2_02_bench_kernel_stats.txt: rocprofv3 --kernel-trace of this command with --no-batches, mean over "
                            "the backward loop's launches (plain and two-step gradient launches weighted by count)",
                 "profile_note": "the tracer slows these ~5 us launches: HIP events around the same loop read 8.7 us "
-                                "per launch under rocprofv3 and 5.6 us without it (profiles/r2_bench_line_under_trace.json "
-                                "vs profiles/r2_bench_line_untraced.json), so the traced kernel-only mean exceeds the "
+                                "per launch under rocprofv3 and 5.6 us without it (profiles/r2_01_bench_line_under_trace.json "
+                                "vs profiles/r2_01_bench_line_untraced.json), so the traced kernel-only mean exceeds the "
                                 "untraced launch-to-launch mean; the 0.9 ms 3-D launch agrees within 1 %",
                 "schedule": "the loop alternates a plain step (step2d_kernel mode 0) and a step that adds the "
                             "gradient terms of both (mode 4); launch time, bytes and traffic are means over the loop"}

@@ -22,7 +22,7 @@ for f in glob.glob(os.path.join(src, "trace", "**", "*kernel_trace.csv"), recurs
     for row in csv.DictReader(open(f)):
         dur[(short(row["Kernel_Name"]), int(row["Grid_Size_X"]) * int(row["Grid_Size_Y"]) * int(row["Grid_Size_Z"]))].append((int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) / 1e3)
 with open(out + "_kernel_stats.txt", "w") as fo:
-    fo.write("# rocprofv3 --kernel-trace of: python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline\n")
+    fo.write("# rocprofv3 --kernel-trace of: python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-batches\n")
     fo.write("# durations in microseconds, per (kernel, grid size in threads)\n")
     fo.write("%-62s %10s %8s %12s %10s %10s %10s\n" % ("kernel", "grid", "calls", "total_us", "avg_us", "min_us", "max_us"))
     for (k, g), v in sorted(dur.items(), key=lambda kv: -sum(kv[1])):
@@ -37,7 +37,7 @@ with open(out + "_pmc.txt", "w") as fo:
     fo.write("# rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate runs) of the same command; means per launch, KiB\n")
     fo.write("# FETCH_SIZE counts 128-byte requests at 64 bytes on gfx950: double it before comparing with a byte count\n")
     for (k, g), cs in sorted(pmc.items()):
-        if "step" not in k and "tti" not in k:
+        if "step" not in k and "tti" not in k and "persist" not in k:
             continue
         fo.write("%-62s grid=%-9d %s\n" % (k[:62], g, "  ".join("%s n=%d mean=%.6g" % (c, len(v), sum(v) / len(v))
                                                                for c, v in sorted(cs.items()))))
@@ -65,18 +65,26 @@ def entry(parts):
 
 # grids of the benchmark: 8 shots x 98 tiles of 32 x 32 (+ 16 interpolation blocks in forward loops), 256 threads;
 # 592^3: 370 tiles x 6 chunks (+ 16 interpolation blocks) forward, 370 x 4 chunks in the gradient loop
-traffic = {"_comment": "Per launch, from rocprofv3 of `python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline`: mean "
+traffic = {"_comment": "Per launch, from rocprofv3 of `python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-batches`: mean "
                        "duration from the kernel trace, fabric-side bytes = 2 x FETCH_SIZE + WRITE_SIZE (FETCH_SIZE "
                        "tallies 128-byte requests at 64 bytes on gfx950). For the 2-D kernels the working set lives in "
                        "the 256 MB last-level cache: these are bytes leaving the L2s, an upper bound on HBM traffic. "
                        "Gradient loops alternate a plain step and a step that adds the gradient terms of both: their "
-                       "entries are means over the launches of the loop."}
+                       "entries are means over the launches of the loop. persist2d_kernel entries: one launch runs a "
+                       "whole time loop (nt - 2 = 1499 steps of 8 shots); the plain variant's launches mix saving "
+                       "forward loops, forward-only loops and none else."}
 spec = {
     "step2d_kernel": [("step2d_kernel<8, 32, 32, 0, 4>", 204800)],
     "step2d_kernel<GRAD>": [("step2d_kernel<8, 32, 32, 0, 4>", 200704), ("step2d_kernel<8, 32, 32, 4, 4>", 200704)],
 }
 for name, parts in spec.items():
     e = entry(parts)
+    if e:
+        traffic[name] = e
+# whole-loop launches of the 2-D time loops (one launch = nt - 2 steps of 8 shots): every grid of the kernel
+for name, frag in (("persist2d_kernel", "persist2d_kernel<8, 32, 32, 0>"), ("persist2d_kernel<GRAD>", "persist2d_kernel<8, 32, 32, 1>")):
+    parts = [(k[0], k[1]) for k in dur if frag in k[0]]
+    e = entry(parts) if parts else None
     if e:
         traffic[name] = e
 # 3-D: take whatever grids the trace holds for the order-16 forward step and the order-8 gradient loop
