@@ -331,6 +331,16 @@ __global__ __launch_bounds__(256, 4) void persist2d_kernel(Persist2DArgs q)
                 for (int i = 0; i < V; ++i)
                     if (z + i < a.n2) po[i] = res[i];
             }
+            if (a.fs && z <= R) {
+                // free surface: row -zi of the z halo mirrors row zi with the opposite sign (see step2d_kernel); the
+                // tiles along the surface read it back with their halo ring
+                float *row0 = reinterpret_cast<float *>(reinterpret_cast<char *>(rot) + out_off + pb) - z;
+#pragma unroll
+                for (int i = 0; i < V; ++i) {
+                    const int zi = z + i;
+                    if (zi >= 1 && zi <= R && zi < a.n2) row0[-zi] = -res[i];
+                }
+            }
             if (GRAD) {
                 vf4 g = *sum_g, il = *sum_il;
 #pragma unroll

@@ -1204,7 +1204,7 @@ static int prepare_save(Plan &p)
 static bool persist_eligible(Plan &p, int nshots, const SparseSet *sampled, bool grad)
 {
     if (!p.persist || p.kind != 1 || p.esize != 4 || p.save_f16) return false;
-    if (p.cfg.flags & (MIFWI_FLAG_ASYNC | MIFWI_FLAG_NO_GRAPH | MIFWI_FLAG_FREE_SURFACE)) return false;
+    if (p.cfg.flags & (MIFWI_FLAG_ASYNC | MIFWI_FLAG_NO_GRAPH)) return false;
     if (!((p.tile_tx == 32 && p.tile_tz == 32) || (p.tile_tx == 16 && p.tile_tz == 64)) || p.vec2d != 4) return false;
     if (p.cfg.nt < 3) return false;
     if ((unsigned long long)p.L.field * 12ull >= (1ull << 31)) return false;   // a shot's three levels behind one descriptor
