@@ -1212,7 +1212,12 @@ static bool persist_eligible(Plan &p, int nshots, const SparseSet *sampled, bool
     int &bpc = p.persist_bpc[grad ? 1 : 0];
     if (bpc < 0) bpc = persist2d_blocks_per_cu(p.L.R, p.tile_tz, grad);
     // every tile of a shot needs a resident block on the shot's XCD for the whole loop
-    return bpc * (p.ncu / 8) >= p.ntx * p.ntz;
+    if (bpc * (p.ncu / 8) < p.ntx * p.ntz) return false;
+    if (p.persist_skip > 0) {   // a launch was abandoned not long ago (the GPU was busy with something else)
+        --p.persist_skip;
+        return false;
+    }
+    return true;
 }
 
 // Queue the launches that run the whole loop -- one per group of 8 shots (one shot per XCD), one group after
@@ -1394,8 +1399,9 @@ static int run_forward(Plan &p, int nshots, int save)
     if (!ckpt && !in_saved && persist_eligible(p, nshots, &p.rec, false)) {
         auto whole_loop = [&](int &n) -> int { return enqueue_persist(p, nshots, true, false, false, copy_save, n); };
         if ((rc = timed_loop(p, nullptr, whole_loop, launches, ms))) return rc;
-        if (*p.h_abort) {   // a block waited too long for a neighbour: never again on this plan, and this loop anew
-            p.persist = 0;
+        if (*p.h_abort) {   // a block waited too long for a neighbour: this loop anew, and the next ones, a kernel per step
+            p.persist_skip = p.persist_backoff;
+            p.persist_backoff = std::min(4096, 2 * p.persist_backoff);
             return run_forward<T>(p, nshots, save);
         }
         p.loop_persist = true;
@@ -1528,7 +1534,8 @@ static int run_backward(Plan &p, int nshots, bool with_grad, bool with_illum)
         auto whole_loop = [&](int &n) -> int { return enqueue_persist(p, nshots, false, with_grad, with_illum, false, n); };
         if ((rc = timed_loop(p, nullptr, whole_loop, launches, ms, true))) return rc;
         if (*p.h_abort) {
-            p.persist = 0;
+            p.persist_skip = p.persist_backoff;
+            p.persist_backoff = std::min(4096, 2 * p.persist_backoff);
             return run_backward<T>(p, nshots, with_grad, with_illum);
         }
         p.loop_persist = true;

@@ -177,7 +177,9 @@ struct Plan {
     int pair_save = 1;  // saving forward loops of the tiled 2-D kernel write two saved levels every second step
     int pair_grad = 1;  // gradient loops update the accumulators every second step (tiled kernels)
     // whole-loop launches of the tiled 2-D kernel's work (kernels_persist2d.hip)
-    int persist = 1;                   // 0: never (MIFWI_PERSIST=0, or a loop had to be abandoned once)
+    int persist = 1;                   // 0: never (MIFWI_PERSIST=0)
+    int persist_skip = 0;              // loops still to run with a kernel per step after a whole-loop launch was abandoned
+    int persist_backoff = 64;          // and how many the next abandoned launch will cost (doubles, up to 4096)
     int persist_spin = 1 << 21;        // polls of a neighbour's counter before a loop is abandoned (MIFWI_PERSIST_SPIN)
     int persist_bpc[2] = {-1, -1};     // resident blocks per CU of the plain / gradient variant, -1 = not asked yet
     int *d_psync = nullptr;            // per-tile step counters [8][tiles], blocks taken per XCD [16], abort flag

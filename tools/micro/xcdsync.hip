@@ -93,6 +93,27 @@ __global__ __launch_bounds__(256) void k_persist(Args a)
         int fail = 0;
         if (nb >= 0) {
             int n = 0;
+            if (a.mode & 512) {
+                // pipelined polling: four loads in flight, a fresh answer every few dozen cycles instead of every
+                // L2 round trip
+                while (true) {
+                    const int v0 = raw_buffer_load_i1(doneB, nb * 4, 0, 16);
+                    __builtin_amdgcn_s_sleep(1);
+                    const int v1 = raw_buffer_load_i1(doneB, nb * 4, 0, 16);
+                    __builtin_amdgcn_s_sleep(1);
+                    const int v2 = raw_buffer_load_i1(doneB, nb * 4, 0, 16);
+                    __builtin_amdgcn_s_sleep(1);
+                    const int v3 = raw_buffer_load_i1(doneB, nb * 4, 0, 16);
+                    if (v0 >= t - 1) break;
+                    if (v1 >= t - 1) break;
+                    if (v2 >= t - 1) break;
+                    if (v3 >= t - 1) break;
+                    if (++n > SPIN_LIMIT) {
+                        fail = 1;
+                        break;
+                    }
+                }
+            } else
             while (flag_load(doneB, nb * 4, a.mode) < t - 1) {
                 if (++n > SPIN_LIMIT || __hip_atomic_load(a.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
                     fail = 1;
