@@ -402,6 +402,11 @@ def shot_batches(mifwi, torch, dev, local_rank, true_model, init_model, rec, so,
 
 
 def main():
+    # The result line is the only thing this program writes to its standard output: libraries that print banners
+    # there (RCCL prints its version when a communicator is created) are pointed at standard error instead.
+    result_out = os.fdopen(os.dup(1), "w")
+    sys.stdout.flush()
+    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
@@ -595,7 +600,8 @@ def main():
     if rank == 0 and world == 1 and not args.no_tti:
         out["config_tti_2d"] = tti_leg(mifwi, local_rank, true_model, src_all, rec)
     if rank == 0:
-        print(json.dumps(out))
+        result_out.write(json.dumps(out) + "\n")
+        result_out.flush()
     if use_dist:
         dist.destroy_process_group()
 
