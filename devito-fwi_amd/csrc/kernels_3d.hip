@@ -78,7 +78,14 @@ __device__ vf4 raw_buffer_load_f4(vi4 rsrc, int voffset, int soffset, int aux) _
 __device__ vf2 raw_buffer_load_f2(vi4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.v2f32");
 __device__ void raw_buffer_store_f4(vf4 v, vi4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.store.v4f32");
 __device__ void raw_buffer_store_f2(vf2 v, vi4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.store.v2f32");
-// descriptor of the memory that starts at p (p is uniform over the block): no stride, no range check
+__device__ void raw_buffer_store_f1(float v, vi4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.store.f32");
+// Descriptor of the memory that starts at p (p is uniform over the block): no stride, and a range of 2 GB - 1
+// bytes.  A lane whose offset is kDead lies outside it: its loads return zeros and its stores are dropped without
+// touching memory (probed on the hardware, tools/micro/bufoob.hip).  Lanes that have nothing to load or store
+// are switched off through their offset, not through a branch around the instruction, so that every plane
+// issues the same sequence of memory instructions and the waits in front of their uses can count the younger
+// ones that may stay in flight (a branch around a load makes the compiler wait for everything).
+constexpr unsigned kDead = 0x80000000u;
 __device__ inline vi4 buf_of(const void *p)
 {
     union {
@@ -89,7 +96,7 @@ __device__ inline vi4 buf_of(const void *p)
         vi4 v;
     } r;
     r.s.p = p;
-    r.s.n = 0xffffffffu;
+    r.s.n = 0x7fffffffu;
     r.s.f = 0x00020000u;
     return r.v;
 }
@@ -106,6 +113,25 @@ __device__ inline void bldv(vi4 b, unsigned soff, unsigned off, float (&d)[V])
 #pragma unroll
         for (int i = 0; i < V; ++i) d[i] = v[i];
     }
+}
+// the points z + i < n2 of a thread's V, one predicated 4-byte store each (the last tile of a row when n2 is not a
+// multiple of V; same descriptor and offsets as the vector store, so the common path keeps no pointer for it)
+template <int V>
+__device__ inline void bstv_ragged(vi4 b, unsigned soff, unsigned off, const float (&d)[V], int nlive)
+{
+#pragma unroll
+    for (int i = 0; i < V; ++i)
+        if (i < nlive) raw_buffer_store_f1(d[i], b, (int)(off + 4 * i), (int)soff, 0);
+}
+// The kernel's own argument block, for branches that are rarely taken: what they need is read from it where
+// they run instead of being held in scalar registers across the march along x (the compiler cannot see that
+// the pointer is the one it already has, so it does not hoist the loads).
+typedef const Step3DArgs __attribute__((address_space(4))) *RareArgs;
+__device__ inline RareArgs rare_args()
+{
+    unsigned long v = (unsigned long)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(v));
+    return (RareArgs)v;
 }
 template <int V>
 __device__ inline void bstv_stream(vi4 b, unsigned soff, unsigned off, const float (&d)[V])
@@ -167,15 +193,12 @@ __device__ inline void lds_stv(float *p, const float (&d)[V])
 }
 
 // R: stencil radius.  TY x TZ: tile of the (y, z) plane.  V: points per thread (TY*TZ/V threads).
-// Register budget: the propagation variants are held to 168 VGPRs (3 blocks of 256 threads per CU;
-// at radius 8 that is 165 without spilling and worth +8 % over 2 blocks), the gradient variant,
-// which carries five more vectors, to 2 blocks per CU.
+// Register budget: the propagation variants are held to 168 VGPRs (3 blocks of 256 threads per CU; they need
+// 139 at radius 8); the gradient variants, which carry five more vectors (163 at radius 8), are launched for 2
+// blocks per CU: a third measured no faster, they are bound by their bytes.
 // GRAD: also accumulate the FWI gradient.  ISO: equal spacing in x, y and z (one coefficient set).
 #ifndef MIFWI_3D_GRAD_WAVES
 #define MIFWI_3D_GRAD_WAVES 2
-#endif
-#ifndef MIFWI_3D_PF_MAXR
-#define MIFWI_3D_PF_MAXR 5
 #endif
 // MODE 0: plain propagation, 1: gradient, 2: scattered field of Born modelling, 3: plain propagation that
 // also streams a half-precision copy of the new level into the saved array, 4: gradient of two steps
@@ -184,9 +207,6 @@ template <int R, int TY, int TZ, int V, int MODE, bool ISO>
 __global__ __launch_bounds__(TY *TZ / V, (MODE == 1 || MODE == 2 || MODE == 4 ? MIFWI_3D_GRAD_WAVES : 3) * (TY * TZ / V) / 256) void step3d_kernel(Step3DArgs a)
 {
     constexpr bool GRAD = (MODE == 1 || MODE == 4), PAIR = (MODE == 4), BORN = (MODE == 2);
-    // PF: the coefficient and old-level loads of plane x + 1 are issued during plane x (one more plane of
-    // lead for 12 more registers); only where the register budget has the room
-    constexpr bool PF = (R <= MIFWI_3D_PF_MAXR) && MODE == 0;
     constexpr int NT = TY * TZ / V;                     // threads per block
     constexpr int RZ = (R + 3) / 4 * 4;
     constexpr int RZ4 = RZ / 4;
@@ -240,8 +260,12 @@ __global__ __launch_bounds__(TY *TZ / V, (MODE == 1 || MODE == 2 || MODE == 4 ? 
     const int y = y0 + ty, z = z0 + V * tq;
     const bool live = (y < a.n1) && (z < a.n2);
     const bool full = (z + V - 1 < a.n2);
+    const int nlive = live ? min(V, a.n2 - z) : 0;   // points of this thread inside the grid
+    const bool fs_rows = a.fs && z <= R;              // rows whose mirror image this thread keeps (free surface)
     // own column: byte offset of (plane 0, y, z) from a level base; planes advance by sb bytes
     const unsigned col = (unsigned)((a.off0 + (long)y * a.s1 + z) * 4);
+    const unsigned col_l = live ? col : kDead;            // as a load offset
+    const unsigned col_s = (live && full) ? col : kDead;  // as the offset of a V-point store
     const long sb = a.s0 * 4;
     const char *cur = reinterpret_cast<const char *>(a.cur + (long)shot * a.shot_stride);
     const char *old = reinterpret_cast<const char *>(a.old + (long)shot * a.shot_stride);
@@ -273,10 +297,11 @@ __global__ __launch_bounds__(TY *TZ / V, (MODE == 1 || MODE == 2 || MODE == 4 ? 
         const int gy = y0 - R + row;
         h_ok[i] = (h < NH) && (gy < a.n1 + R);
         h_lds[i] = row * P + 4 * c4;
-        h_glb[i] = (unsigned)((a.off0 + (long)gy * a.s1 + (z0 - RZ + 4 * c4)) * 4);
+        h_glb[i] = h_ok[i] ? (unsigned)((a.off0 + (long)gy * a.s1 + (z0 - RZ + 4 * c4)) * 4) : kDead;
     }
 
-    const unsigned char *ezero = a.eta_zero ? a.eta_zero + (long)tile * a.n0 : nullptr;
+    // planes ef_lo <= x < ef_hi of this tile are free of the sponge: they skip its 4 bytes per point
+    const int ef_lo = a.eta_free ? a.eta_free[2 * tile] : 0, ef_hi = a.eta_free ? a.eta_free[2 * tile + 1] : 0;
 
     // injection work of this block: CSR over (tile, plane), ranges for the whole chunk
     const int inj_tab = a.inj_per_shot ? shot : 0;
@@ -287,33 +312,24 @@ __global__ __launch_bounds__(TY *TZ / V, (MODE == 1 || MODE == 2 || MODE == 4 ? 
     float q[2 * R + 1][V], qn[V];
 #pragma unroll
     for (int j = 0; j < 2 * R; ++j) {
-#pragma unroll
-        for (int i = 0; i < V; ++i) q[j + 1][i] = 0.f;
-        if (live) bldv<V>(curB, (unsigned)(xa + j) * sbu, col, q[j + 1]);
+        bldv<V>(curB, (unsigned)(xa + j) * sbu, col_l, q[j + 1]);
     }
-#pragma unroll
-    for (int i = 0; i < V; ++i) qn[i] = 0.f;
-    if (live) bldv<V>(curB, (unsigned)(xa + 2 * R) * sbu, col, qn);
+    bldv<V>(curB, (unsigned)(xa + 2 * R) * sbu, col_l, qn);
     float hv[NHT][4];
 #pragma unroll
-    for (int i = 0; i < NHT; ++i) {
-        hv[i][0] = hv[i][1] = hv[i][2] = hv[i][3] = 0.f;
-        if (h_ok[i]) bldv<4>(curB, (unsigned)(xa + R) * sbu, h_glb[i], hv[i]);
-    }
+    for (int i = 0; i < NHT; ++i) bldv<4>(curB, (unsigned)(xa + R) * sbu, h_glb[i], hv[i]);
 
-    float mm_n[V], ee_n[V], oo_n[V];
-    if (PF) {
+    // The result of a plane is stored at the start of the NEXT plane, ahead of that plane's loads: a wait for a
+    // load then never has a younger store in front of it (the compiler's waits let the youngest loads stay in
+    // flight but count no store among them, so a store issued just before the wait would have to complete first).
+    float res_p[V];
 #pragma unroll
-        for (int i = 0; i < V; ++i) mm_n[i] = 1.f, ee_n[i] = 0.f, oo_n[i] = 0.f;
-        if (live) {
-            bldv<V, kBufStream>(mB, (unsigned)xa * sbu, col, mm_n);
-            if (!(ezero && ezero[xa] != 0)) bldv<V, kBufStream>(eB, (unsigned)xa * sbu, col, ee_n);
-            bldv<V, kBufStream>(oldB, (unsigned)xa * sbu, col, oo_n);
-        }
-    }
+    for (int i = 0; i < V; ++i) res_p[i] = 0.f;
+    unsigned soff_p = 0, col_p = kDead;
 
     int buf = 0;
     for (int x = xa; x < xb; ++x) {
+        bstv_stream<V>(outB, soff_p, col_p, res_p);
         // advance the queue: plane x+R arrived during the previous plane, x+R+1 is requested now
 #pragma unroll
         for (int j = 0; j < 2 * R; ++j) {
@@ -322,21 +338,14 @@ __global__ __launch_bounds__(TY *TZ / V, (MODE == 1 || MODE == 2 || MODE == 4 ? 
         }
 #pragma unroll
         for (int i = 0; i < V; ++i) q[2 * R][i] = qn[i];
-        if (live && x + 1 < xb) bldv<V>(curB, (unsigned)(x + 2 * R + 1) * sbu, col, qn);
+        if (x + 1 < xb) bldv<V>(curB, (unsigned)(x + 2 * R + 1) * sbu, col_l, qn);
         // this plane's coefficients are only needed once the stencil sum is complete
         float mm[V], ee[V], oo[V];
+        bldv<V, kBufStream>(mB, (unsigned)x * sbu, col_l, mm);
 #pragma unroll
-        for (int i = 0; i < V; ++i) mm[i] = 1.f, ee[i] = 0.f, oo[i] = 0.f;
-        // planes of the tile where the sponge is identically zero skip its 4 bytes per point
-        const bool eta_is_zero = ezero ? (ezero[x] != 0) : false;   // block-uniform
-        if (PF) {
-#pragma unroll
-            for (int i = 0; i < V; ++i) mm[i] = mm_n[i], ee[i] = ee_n[i], oo[i] = oo_n[i];
-        } else if (live) {
-            bldv<V, kBufStream>(mB, (unsigned)x * sbu, col, mm);
-            if (!eta_is_zero) bldv<V, kBufStream>(eB, (unsigned)x * sbu, col, ee);
-            bldv<V, kBufStream>(oldB, (unsigned)x * sbu, col, oo);
-        }
+        for (int i = 0; i < V; ++i) ee[i] = 0.f;
+        if (!(x >= ef_lo && x < ef_hi)) bldv<V, kBufStream>(eB, (unsigned)x * sbu, col_l, ee);
+        bldv<V, kBufStream>(oldB, (unsigned)x * sbu, col_l, oo);
 
         // accumulators and saved level(s) of this plane: issued with the coefficient loads, used last
         float u0[V], up[V], g[V], il[V], po[V];
@@ -346,23 +355,23 @@ __global__ __launch_bounds__(TY *TZ / V, (MODE == 1 || MODE == 2 || MODE == 4 ? 
             for (int i = 0; i < V; ++i) u0[i] = up[i] = g[i] = il[i] = po[i] = 0.f;
             gradb = reinterpret_cast<char *>(a.grad + (long)shot * a.g_shot_stride) + (long)x * sb;
             illumb = a.illum ? reinterpret_cast<char *>(a.illum + (long)shot * a.g_shot_stride) + (long)x * sb : nullptr;
-            if (live) {
-                const long us = (long)shot * a.u_shot_stride * 4 + (long)x * sb;
-                if (a.save_scale) {   // half-precision saved levels (uniform branch)
+            if (a.save_scale) {   // half-precision saved levels (uniform branch)
+                if (live) {
+                    const long us = (long)shot * a.u_shot_stride * 4 + (long)x * sb;
                     const float inv = 1.0f / a.save_scale[shot];
                     ldv_half_stream<V>(reinterpret_cast<const char *>(a.uc) + (us >> 1), col, inv, u0);
                     if (PAIR || (a.first && illumb))
                         ldv_half_stream<V>(reinterpret_cast<const char *>(a.up) + (us >> 1), col, inv, up);
-                } else {
-                    const long ub = (long)shot * a.u_shot_stride * 4;
-                    bldv<V, kBufStream>(buf_of(reinterpret_cast<const char *>(a.uc) + ub), (unsigned)x * sbu, col, u0);
-                    if (PAIR || (a.first && illumb))
-                        bldv<V, kBufStream>(buf_of(reinterpret_cast<const char *>(a.up) + ub), (unsigned)x * sbu, col, up);
                 }
-                if (PAIR) bldv<V, kBufStream>(outB, (unsigned)x * sbu, col, po);   // backward level time + 2, about to be overwritten
-                bldv<V, kBufStream>(buf_of(gradb - (long)x * sb), (unsigned)x * sbu, col, g);
-                if (illumb) bldv<V, kBufStream>(buf_of(illumb - (long)x * sb), (unsigned)x * sbu, col, il);
+            } else {
+                const long ub = (long)shot * a.u_shot_stride * 4;
+                bldv<V, kBufStream>(buf_of(reinterpret_cast<const char *>(a.uc) + ub), (unsigned)x * sbu, col_l, u0);
+                if (PAIR || (a.first && illumb))
+                    bldv<V, kBufStream>(buf_of(reinterpret_cast<const char *>(a.up) + ub), (unsigned)x * sbu, col_l, up);
             }
+            if (PAIR) bldv<V, kBufStream>(outB, (unsigned)x * sbu, col_l, po);   // backward level time + 2, about to be overwritten
+            bldv<V, kBufStream>(buf_of(gradb - (long)x * sb), (unsigned)x * sbu, col_l, g);
+            if (illumb) bldv<V, kBufStream>(buf_of(illumb - (long)x * sb), (unsigned)x * sbu, col_l, il);
         }
 
         // stage plane x: centre from the queue, ring from the registers loaded one plane ago
@@ -374,15 +383,16 @@ __global__ __launch_bounds__(TY *TZ / V, (MODE == 1 || MODE == 2 || MODE == 4 ? 
 
         // injected terms of the cells this tile owns in plane x (rare)
         int inj_beg = 0, inj_end = 0;
-        if (any_inj) {
+        if (__builtin_expect(any_inj, 0)) {
             inj_beg = cptr[x];
             inj_end = cptr[x + 1];
-            if (inj_beg < inj_end) {
+            if (__builtin_expect(inj_beg < inj_end, 0)) {
+                const auto *ra = rare_args();
                 for (int j = tid; j < TY * TZ; j += NT) acc[j] = 0.f;
                 __syncthreads();
-                const float *w = a.winj + ((long)shot * a.nt + a.time) * a.winj_stride;
-                for (int j = inj_beg + tid; j < inj_end; j += NT)
-                    acc[a.cell_local[(long)inj_tab * a.inj_kmax + j]] = w[j];
+                const float *w = ra->winj + ((long)shot * ra->nt + ra->time) * ra->winj_stride;
+                const int32_t *cl = ra->cell_local + (long)(ra->inj_per_shot ? shot : 0) * ra->inj_kmax;
+                for (int j = inj_beg + tid; j < inj_end; j += NT) acc[cl[j]] = w[j];
             }
         }
         __syncthreads();
@@ -390,17 +400,7 @@ __global__ __launch_bounds__(TY *TZ / V, (MODE == 1 || MODE == 2 || MODE == 4 ? 
         // request the next plane's ring before the arithmetic
         if (x + 1 < xb) {
 #pragma unroll
-            for (int i = 0; i < NHT; ++i)
-                if (h_ok[i]) bldv<4>(curB, (unsigned)(x + 1 + R) * sbu, h_glb[i], hv[i]);
-            if (PF) {
-#pragma unroll
-                for (int i = 0; i < V; ++i) ee_n[i] = 0.f;
-                if (live) {
-                    bldv<V, kBufStream>(mB, (unsigned)(x + 1) * sbu, col, mm_n);
-                    if (!(ezero && ezero[x + 1] != 0)) bldv<V, kBufStream>(eB, (unsigned)(x + 1) * sbu, col, ee_n);
-                    bldv<V, kBufStream>(oldB, (unsigned)(x + 1) * sbu, col, oo_n);
-                }
-            }
+            for (int i = 0; i < NHT; ++i) bldv<4>(curB, (unsigned)(x + 1 + R) * sbu, h_glb[i], hv[i]);
         }
         float bn[V], bc[V], bo[V], bd[V];
         if (BORN) {
@@ -414,31 +414,44 @@ __global__ __launch_bounds__(TY *TZ / V, (MODE == 1 || MODE == 2 || MODE == 4 ? 
                 ldv_stream<V>(reinterpret_cast<const char *>(a.b_dm) + (long)x * sb, col, bd);
             }
         }
+        float res[V], uc[V];
+#pragma unroll
+        for (int i = 0; i < V; ++i) res[i] = uc[i] = 0.f;
         if (live) {
             const float *ctr = &L[(ty + R) * P + RZ + V * tq];
-            // every neighbour value is folded into the sums as soon as it is read (one FMA per
-            // value and output: the same count as pairing symmetric neighbours first, with far
-            // shorter register live ranges)
-            float lap[V], uc[V];
+            // The sums are formed for PAIRS of neighbouring outputs (packed two-float multiply-adds), and every
+            // multiply-add gives both outputs of a pair the SAME coefficient: the z line is walked as pairs of
+            // consecutive values (line[k], line[k+1]), each of which serves output pair p at distance
+            // d = k - RZ - 2p.  (Broadcasting one value to a pair of outputs instead needs every ordered pair of
+            // coefficients in scalar registers: about sixty of them at radius 8, most of them spilled and read
+            // back for every plane.)  Values are folded into the sums as soon as they are read.
+            constexpr int NP = V / 2;
+            vf2 lap2[NP];
+            float line[V + 2 * RZ];
 #pragma unroll
-            for (int i = 0; i < V; ++i) lap[i] = 0.f;
+            for (int p = 0; p < NP; ++p) lap2[p] = vf2{0.f, 0.f};
 #pragma unroll
             for (int s = 0; s < (V + 2 * RZ) / V; ++s) {
                 float fv[V];
                 lds_ldv<V>(ctr - RZ + V * s, fv);
 #pragma unroll
-                for (int e = 0; e < V; ++e) {
-                    const int pos = V * s + e - RZ;          // z offset of this value from output 0
-                    if (pos >= 0 && pos < V) uc[pos] = fv[e];
+                for (int e = 0; e < V; ++e) line[V * s + e] = fv[e];
 #pragma unroll
-                    for (int i = 0; i < V; ++i) {
-                        const int d = pos - i;               // neighbour distance for output i
-                        if (d != 0 && d >= -R && d <= R) lap[i] += a.cz[d < 0 ? -d : d] * fv[e];
+                for (int k = V * s - 1; k <= V * s + V - 2; ++k) {
+                    if (k < 0) continue;
+                    const vf2 pk = vf2{line[k], line[k + 1]};
+#pragma unroll
+                    for (int p = 0; p < NP; ++p) {
+                        const int d = k - RZ - 2 * p;        // neighbour distance for both outputs of pair p
+                        const int ad = d < 0 ? -d : d;
+                        if (ad >= 1 && ad <= R) lap2[p] = __builtin_elementwise_fma(vf2{a.cz[ad], a.cz[ad]}, pk, lap2[p]);
                     }
                 }
             }
 #pragma unroll
-            for (int i = 0; i < V; ++i) lap[i] += a.c0 * uc[i];
+            for (int i = 0; i < V; ++i) uc[i] = line[RZ + i];
+#pragma unroll
+            for (int p = 0; p < NP; ++p) lap2[p] = __builtin_elementwise_fma(vf2{a.c0, a.c0}, vf2{uc[2 * p], uc[2 * p + 1]}, lap2[p]);
 #pragma unroll
             for (int k = 1; k <= R; ++k) {
                 const float cyk = ISO ? a.cz[k] : a.cy[k];
@@ -446,19 +459,23 @@ __global__ __launch_bounds__(TY *TZ / V, (MODE == 1 || MODE == 2 || MODE == 4 ? 
                 lds_ldv<V>(ctr - k * P, lo);
                 lds_ldv<V>(ctr + k * P, hi);
 #pragma unroll
-                for (int i = 0; i < V; ++i) lap[i] += cyk * lo[i];
+                for (int p = 0; p < NP; ++p) lap2[p] = __builtin_elementwise_fma(vf2{cyk, cyk}, vf2{lo[2 * p], lo[2 * p + 1]}, lap2[p]);
 #pragma unroll
-                for (int i = 0; i < V; ++i) lap[i] += cyk * hi[i];
+                for (int p = 0; p < NP; ++p) lap2[p] = __builtin_elementwise_fma(vf2{cyk, cyk}, vf2{hi[2 * p], hi[2 * p + 1]}, lap2[p]);
             }
 #pragma unroll
             for (int k = 1; k <= R; ++k) {
                 const float cxk = ISO ? a.cz[k] : a.cx[k];
 #pragma unroll
-                for (int i = 0; i < V; ++i) lap[i] += cxk * q[R - k][i];
+                for (int p = 0; p < NP; ++p)
+                    lap2[p] = __builtin_elementwise_fma(vf2{cxk, cxk}, vf2{q[R - k][2 * p], q[R - k][2 * p + 1]}, lap2[p]);
 #pragma unroll
-                for (int i = 0; i < V; ++i) lap[i] += cxk * q[R + k][i];
+                for (int p = 0; p < NP; ++p)
+                    lap2[p] = __builtin_elementwise_fma(vf2{cxk, cxk}, vf2{q[R + k][2 * p], q[R + k][2 * p + 1]}, lap2[p]);
             }
-            float res[V];
+            float lap[V];
+#pragma unroll
+            for (int i = 0; i < V; ++i) lap[i] = lap2[i / 2][i % 2];
 #pragma unroll
             for (int i = 0; i < V; ++i) {
                 const float ed = ee[i] * a.dt;
@@ -471,37 +488,9 @@ __global__ __launch_bounds__(TY *TZ / V, (MODE == 1 || MODE == 2 || MODE == 4 ? 
                     res[i] += fast_div3(a.dt2 * (-bd[i] * utt), mm[i] + ee[i] * a.dt);
                 }
             }
-            if (inj_beg < inj_end) {
+            if (__builtin_expect(inj_beg < inj_end, 0)) {
 #pragma unroll
                 for (int i = 0; i < V; ++i) res[i] += acc[ty * TZ + V * tq + i];
-            }
-            if (full) {
-                bstv_stream<V>(outB, (unsigned)x * sbu, col, res);
-            } else {
-                float *po = reinterpret_cast<float *>(out + (long)x * sb + col);
-                for (int i = 0; i < V; ++i)
-                    if (z + i < a.n2) po[i] = res[i];
-            }
-            if (MODE == 3) {
-                // half-precision copy of the new level into the saved array
-                const float sc = a.save_scale[shot];
-                char *cb = reinterpret_cast<char *>(a.copy16) + (((long)shot * a.copy_shot_stride * 4 + (long)x * sb) >> 1);
-                if (full) {
-                    stv_half_stream<V>(cb, col, res, sc);
-                } else {
-                    __half *ch = reinterpret_cast<__half *>(cb + (col >> 1));
-                    for (int i = 0; i < V; ++i)
-                        if (z + i < a.n2) ch[i] = __float2half_rn(fminf(fmaxf(res[i] * sc, -65504.0f), 65504.0f));
-                }
-            }
-            if (a.fs && z <= R) {
-                // free surface: antisymmetric mirror of rows 1..R into the z halo (see kernels_tiled2d.hip)
-                float *po = reinterpret_cast<float *>(out + (long)x * sb + col);
-#pragma unroll
-                for (int i = 0; i < V; ++i) {
-                    const int zi = z + i;
-                    if (zi >= 1 && zi <= R && zi < a.n2) po[-z - zi] = -res[i];
-                }
             }
             if (GRAD) {
                 if (PAIR) {
@@ -522,23 +511,48 @@ __global__ __launch_bounds__(TY *TZ / V, (MODE == 1 || MODE == 2 || MODE == 4 ? 
                     else
                         il[i] = illum_accumulate(il[i], u0[i]);
                 }
-                if (full) {
-                    bstv_stream<V>(buf_of(gradb - (long)x * sb), (unsigned)x * sbu, col, g);
-                    if (illumb) bstv_stream<V>(buf_of(illumb - (long)x * sb), (unsigned)x * sbu, col, il);
-                } else {
-                    float *pg = reinterpret_cast<float *>(gradb + col);
-                    float *pi = illumb ? reinterpret_cast<float *>(illumb + col) : nullptr;
-                    for (int i = 0; i < V; ++i)
-                        if (z + i < a.n2) {
-                            pg[i] = g[i];
-                            if (pi) pi[i] = il[i];
-                        }
-                }
             }
         }
-        if (inj_beg < inj_end) __syncthreads();   // acc is rewritten by the next plane that injects
+        // results: one V-point store per thread (dropped for lanes outside the grid); a thread that straddles
+        // the end of a row stores its points one by one
+        const bool ragged = !full && nlive > 0;
+#pragma unroll
+        for (int i = 0; i < V; ++i) res_p[i] = res[i];
+        soff_p = (unsigned)x * sbu, col_p = col_s;
+        if (__builtin_expect(ragged, 0)) bstv_ragged<V>(outB, (unsigned)x * sbu, col, res, nlive);
+        if (MODE == 3 && live) {
+            // half-precision copy of the new level into the saved array
+            const float sc = a.save_scale[shot];
+            char *cb = reinterpret_cast<char *>(a.copy16) + (((long)shot * a.copy_shot_stride * 4 + (long)x * sb) >> 1);
+            if (full) {
+                stv_half_stream<V>(cb, col, res, sc);
+            } else {
+                __half *ch = reinterpret_cast<__half *>(cb + (col >> 1));
+                for (int i = 0; i < V; ++i)
+                    if (z + i < a.n2) ch[i] = __float2half_rn(fminf(fmaxf(res[i] * sc, -65504.0f), 65504.0f));
+            }
+        }
+        if (__builtin_expect(fs_rows && live, 0)) {
+            // free surface: antisymmetric mirror of rows 1..R into the z halo (see kernels_tiled2d.hip)
+#pragma unroll
+            for (int i = 0; i < V; ++i) {
+                const int zi = z + i;
+                if (zi >= 1 && zi <= R && i < nlive)
+                    raw_buffer_store_f1(-res[i], outB, (int)(col - 4u * (unsigned)(z + zi)), (int)((unsigned)x * sbu), 0);
+            }
+        }
+        if (GRAD) {
+            bstv_stream<V>(buf_of(gradb - (long)x * sb), (unsigned)x * sbu, col_s, g);
+            if (illumb) bstv_stream<V>(buf_of(illumb - (long)x * sb), (unsigned)x * sbu, col_s, il);
+            if (__builtin_expect(ragged, 0)) {
+                bstv_ragged<V>(buf_of(gradb - (long)x * sb), (unsigned)x * sbu, col, g, nlive);
+                if (illumb) bstv_ragged<V>(buf_of(illumb - (long)x * sb), (unsigned)x * sbu, col, il, nlive);
+            }
+        }
+        if (__builtin_expect(inj_beg < inj_end, 0)) __syncthreads();   // acc is rewritten by the next plane that injects
         buf ^= 1;
     }
+    bstv_stream<V>(outB, soff_p, col_p, res_p);
 }
 
 // eta_zero[tile][x] = 1 when the sponge field vanishes on the whole (tile, plane) patch
@@ -556,11 +570,31 @@ __global__ void eta_zero_kernel(const float *eta, unsigned char *flags, int n0, 
     if (threadIdx.x == 0) flags[blockIdx.x] = nonzero ? 0 : 1;
 }
 
-int launch_eta_zero(const Plan &p, unsigned char *flags)
+// free_range[tile] = the longest run lo <= x < hi of planes whose flag is set (one thread per tile)
+__global__ void eta_free_kernel(const unsigned char *flags, int *free_range, int ntiles, int n0)
 {
-    const int nblocks = p.ntx * p.ntz * p.L.n[0];
+    const int tile = blockIdx.x * blockDim.x + threadIdx.x;
+    if (tile >= ntiles) return;
+    int best_lo = 0, best_hi = 0, lo = 0;
+    for (int x = 0; x <= n0; ++x) {
+        if (x == n0 || !flags[(long)tile * n0 + x]) {
+            if (x - lo > best_hi - best_lo) best_lo = lo, best_hi = x;
+            lo = x + 1;
+        }
+    }
+    free_range[2 * tile] = best_lo;
+    free_range[2 * tile + 1] = best_hi;
+}
+
+int launch_eta_zero(const Plan &p, unsigned char *flags, int *free_range)
+{
+    const int ntiles = p.ntx * p.ntz;
+    const int nblocks = ntiles * p.L.n[0];
     hipLaunchKernelGGL(eta_zero_kernel, dim3(nblocks), dim3(256), 0, p.stream, (const float *)p.eta, flags, p.L.n[0],
                        p.L.n[1], p.L.n[2], p.L.s0, p.L.s1, p.L.off0, p.ntz, p.tile_tx, p.tile_tz);
+    MIFWI_HIP(hipGetLastError());
+    hipLaunchKernelGGL(eta_free_kernel, dim3((ntiles + 63) / 64), dim3(64), 0, p.stream, (const unsigned char *)flags,
+                       free_range, ntiles, p.L.n[0]);
     MIFWI_HIP(hipGetLastError());
     return MIFWI_OK;
 }

@@ -184,6 +184,7 @@ static void destroy(Plan *p)
     dev_free(p->d_partial);
     dev_free(p->d_fval);
     dev_free(p->eta_zero);
+    dev_free(p->eta_free);
     for (auto &pair : p->ev)
         for (hipEvent_t e : pair)
             if (e) (void)hipEventDestroy(e);
@@ -544,8 +545,9 @@ static int create(const mifwi_config *cfg, mifwi_plan **out)
         if (const char *env = getenv("MIFWI_3D_SLAB_CHUNKS")) p->slab_chunks = std::max(1, atoi(env));
         if (p->slab_w > 0 && p->slab_w < 2 * p->L.R) p->slab_w = 2 * p->L.R;
     }
-    // the tiled kernels address a field level with 32-bit byte offsets
-    if (p->kind != 0 && (unsigned long long)p->L.field * 4ull >= (1ull << 32)) p->kind = 0;
+    // the tiled kernels address a field level with 32-bit byte offsets; the 2.5-D kernel's buffer descriptors
+    // span 2 GB - 1 bytes (offsets beyond that switch a lane off)
+    if (p->kind != 0 && (unsigned long long)p->L.field * 4ull >= (p->kind == 2 ? 0x7fff0000ull : (1ull << 32))) p->kind = 0;
     auto bail = [&](int code) {
         destroy(p);
         return code;
@@ -610,7 +612,8 @@ static int set_model(Plan &p, const void *vp, const void *damp)
     if (p.tti_ck_K > 0) p.tti_save_valid = false;
     if (p.kind == 2) {
         if (!p.eta_zero && (rc = dev_alloc(p, (void **)&p.eta_zero, (size_t)p.ntx * p.ntz * p.L.n[0], true))) return rc;
-        if ((rc = launch_eta_zero(p, p.eta_zero))) return rc;
+        if (!p.eta_free && (rc = dev_alloc(p, (void **)&p.eta_free, (size_t)p.ntx * p.ntz * 2 * sizeof(int), true))) return rc;
+        if ((rc = launch_eta_zero(p, p.eta_zero, p.eta_free))) return rc;
     }
     p.have_model = true;
     // pageable host sources must not be reused by the caller before the copy has happened
@@ -841,7 +844,7 @@ static Step3DArgs base3d(const Plan &p, int nshots, bool grad)
     a.x_lo = 0, a.x_hi = p.L.n[0];
     a.nshots = nshots;
     a.nwork = p.ntx * p.ntz * a.nchunk * nshots;
-    a.eta_zero = p.eta_zero;
+    a.eta_free = p.eta_free;
     a.m = (const float *)p.m;
     a.eta = (const float *)p.eta;
     a.nt = p.cfg.nt;

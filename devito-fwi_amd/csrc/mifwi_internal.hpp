@@ -171,7 +171,8 @@ struct Plan {
     int ncu = 256, bpc_fwd = 2, bpc_grad = 2;  // CUs and resident 2.5-D blocks per CU (plain / gradient)
     int nchunk_env = 0;
     int slab_w = 0, slab_chunks = 1;   // two-step sweeps of the 2.5-D kernel: planes per slab (0 = off), chunks per slab
-    unsigned char *eta_zero = nullptr;  // 2.5-D kernel: [tile][n0] flags of sponge-free patches
+    unsigned char *eta_zero = nullptr;  // 2.5-D kernel: [tile][n0] flags of sponge-free patches (scratch of the next)
+    int *eta_free = nullptr;            // 2.5-D kernel: [tile][2] longest run lo <= x < hi of sponge-free planes
     int vec3d = 0;  // points per thread of the 2.5-D kernel: 0 = by stencil radius, else 2 or 4
     int vec2d = 4;      // points per thread of the tiled 2-D kernel (2: experiment, 32 x 32 tiles only)
     int pair_save = 1;  // saving forward loops of the tiled 2-D kernel write two saved levels every second step
@@ -446,7 +447,7 @@ struct Step3DArgs {
     long s0, s1, off0;
     int nty, ntz, nchunk, xchunk, nwork, nshots;
     int x_lo, x_hi;   // planes this launch updates: x_lo <= x < x_hi, split into nchunk chunks of xchunk planes
-    const unsigned char *eta_zero;   // [tile][n0] sponge-free flags, or null
+    const int *eta_free;   // [tile][2]: planes lo <= x < hi of the tile's column are free of the sponge; or null
     // gradient (um == nullptr: plain propagation)
     const float *um, *uc, *up;
     long u_shot_stride;
@@ -478,7 +479,7 @@ struct Step3DArgs {
     const float *save_scale;
 };
 int launch_step3d(const Plan &p, const Step3DArgs &a, hipStream_t stream);
-int launch_eta_zero(const Plan &p, unsigned char *flags);
+int launch_eta_zero(const Plan &p, unsigned char *flags, int *free_range);
 int step3d_blocks_per_cu(int R, bool grad);
 
 
