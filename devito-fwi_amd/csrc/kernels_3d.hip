@@ -232,7 +232,7 @@ __global__ __launch_bounds__(TY *TZ / V, (MODE == 1 || MODE == 2 || MODE == 4 ? 
         const int tab = a.itp_per_shot ? shot : 0;
         const int32_t *idx = a.pt_idx + ((long)tab * a.itp_npoint + pnt) * 8;
         const float *w = a.pt_w + ((long)tab * a.itp_npoint + pnt) * 8;
-        const float *f = a.cur + (long)shot * a.shot_stride;
+        const float *f = (a.pt ? a.pt : a.cur) + (long)shot * a.shot_stride;
         float sum = 0.f;
 #pragma unroll
         for (int c = 0; c < 8; ++c) sum += w[c] * f[idx[c]];
@@ -267,9 +267,9 @@ __global__ __launch_bounds__(TY *TZ / V, (MODE == 1 || MODE == 2 || MODE == 4 ? 
     const unsigned col_l = live ? col : kDead;            // as a load offset
     const unsigned col_s = (live && full) ? col : kDead;  // as the offset of a V-point store
     const long sb = a.s0 * 4;
-    const char *cur = reinterpret_cast<const char *>(a.cur + (long)shot * a.shot_stride);
+    const char *cur = reinterpret_cast<const char *>(a.cur + (long)shot * (a.cur_shot_stride ? a.cur_shot_stride : a.shot_stride));
     const char *old = reinterpret_cast<const char *>(a.old + (long)shot * a.shot_stride);
-    char *out = reinterpret_cast<char *>(a.out + (long)shot * a.shot_stride);
+    char *out = reinterpret_cast<char *>(a.out + (long)shot * (a.out_shot_stride ? a.out_shot_stride : a.shot_stride));
     const char *mb = reinterpret_cast<const char *>(a.m);
     const char *eb = reinterpret_cast<const char *>(a.eta);
     // descriptors: the stencilled level starts R planes early so that plane offsets are never negative
@@ -346,6 +346,14 @@ __global__ __launch_bounds__(TY *TZ / V, (MODE == 1 || MODE == 2 || MODE == 4 ? 
         for (int i = 0; i < V; ++i) ee[i] = 0.f;
         if (!(x >= ef_lo && x < ef_hi)) bldv<V, kBufStream>(eB, (unsigned)x * sbu, col_l, ee);
         bldv<V, kBufStream>(oldB, (unsigned)x * sbu, col_l, oo);
+        // fourth-order-in-time kernel (see Step2DArgs): the level itself when the stencilled field is z, and the
+        // biharmonic term of the saved level in gradient launches (both block-uniform)
+        float ptv[V], bhv[V];
+#pragma unroll
+        for (int i = 0; i < V; ++i) ptv[i] = bhv[i] = 0.f;
+        if (a.pt) bldv<V>(buf_of(reinterpret_cast<const char *>(a.pt + (long)shot * a.shot_stride)), (unsigned)x * sbu, col_l, ptv);
+        if (GRAD && a.bih)
+            bldv<V, kBufStream>(buf_of(reinterpret_cast<const char *>(a.bih + (long)shot * a.g_shot_stride)), (unsigned)x * sbu, col_l, bhv);
 
         // accumulators and saved level(s) of this plane: issued with the coefficient loads, used last
         float u0[V], up[V], g[V], il[V], po[V];
@@ -476,10 +484,21 @@ __global__ __launch_bounds__(TY *TZ / V, (MODE == 1 || MODE == 2 || MODE == 4 ? 
             float lap[V];
 #pragma unroll
             for (int i = 0; i < V; ++i) lap[i] = lap2[i / 2][i % 2];
+            if (a.pt) {   // the stencilled field was z; the pointwise terms take the level itself
 #pragma unroll
-            for (int i = 0; i < V; ++i) {
-                const float ed = ee[i] * a.dt;
-                res[i] = fast_div3(a.dt2 * lap[i] + 2.0f * mm[i] * uc[i] - mm[i] * oo[i] + ed * uc[i], mm[i] + ed);
+                for (int i = 0; i < V; ++i) uc[i] = ptv[i];
+            }
+            if (MODE == 0 && a.pre_mode) {   // block-uniform: a field derived from `cur`, not a time step
+#pragma unroll
+                for (int i = 0; i < V; ++i)
+                    res[i] = a.pre_mode == 1 ? uc[i] + fast_div3(a.pre_c * lap[i], mm[i])
+                                             : (a.pre_mode == 2 ? fast_div3(lap[i], mm[i] * mm[i]) : lap[i]);
+            } else {
+#pragma unroll
+                for (int i = 0; i < V; ++i) {
+                    const float ed = ee[i] * a.dt;
+                    res[i] = fast_div3(a.dt2 * lap[i] + 2.0f * mm[i] * uc[i] - mm[i] * oo[i] + ed * uc[i], mm[i] + ed);
+                }
             }
             if (BORN) {
 #pragma unroll
@@ -510,6 +529,10 @@ __global__ __launch_bounds__(TY *TZ / V, (MODE == 1 || MODE == 2 || MODE == 4 ? 
                         il[i] = illum_accumulate(illum_accumulate(il[i], up[i]), u0[i]);   // levels nt-1, nt-2
                     else
                         il[i] = illum_accumulate(il[i], u0[i]);
+                }
+                if (a.bih) {
+#pragma unroll
+                    for (int i = 0; i < V; ++i) g[i] = __builtin_fmaf(-(a.pre_c * bhv[i]), uc[i], g[i]);
                 }
             }
         }

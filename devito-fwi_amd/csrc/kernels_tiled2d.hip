@@ -181,7 +181,7 @@ __global__ __launch_bounds__(TX *TZ / V, V == 2 ? MIFWI_2D_V2_BLOCKS : ((MODE ==
         const int tab = a.itp_per_shot ? shot : 0;
         const int4 idx = *reinterpret_cast<const int4 *>(a.pt_idx + ((long)tab * a.itp_npoint + pnt) * 4);
         const float4 w = *reinterpret_cast<const float4 *>(a.pt_w + ((long)tab * a.itp_npoint + pnt) * 4);
-        const float *f = a.cur + (long)shot * a.shot_stride;
+        const float *f = (a.pt ? a.pt : a.cur) + (long)shot * a.shot_stride;
         const float sum = w.x * f[idx.x] + w.y * f[idx.y] + w.z * f[idx.z] + w.w * f[idx.w];
         a.vals_out[((long)shot * a.nt + a.time) * a.itp_npoint + pnt] = sum;
         return;
@@ -196,11 +196,13 @@ __global__ __launch_bounds__(TX *TZ / V, V == 2 ? MIFWI_2D_V2_BLOCKS : ((MODE ==
     const int x = x0 + tx, z = z0 + V * tq;
     const bool live = (x < a.n1) && (z < a.n2);
     const long p = a.off0 + (long)x * a.s1 + z;
-    const long ps = (long)shot * a.shot_stride + p;
+    const long cur_ss = a.cur_shot_stride ? a.cur_shot_stride : a.shot_stride;
+    const long out_ss = a.out_shot_stride ? a.out_shot_stride : a.shot_stride;
+    const long ps = (long)shot * out_ss + p;   // of `out`
     const unsigned pb = ((unsigned)a.off0 + (unsigned)x * (unsigned)a.s1 + (unsigned)z) * 4u;   // byte offset of (x, z)
-    const char *curb = reinterpret_cast<const char *>(a.cur + (long)shot * a.shot_stride);
+    const char *curb = reinterpret_cast<const char *>(a.cur + (long)shot * cur_ss);
     const char *oldb = reinterpret_cast<const char *>(a.old + (long)shot * a.shot_stride);
-    char *outb = reinterpret_cast<char *>(a.out + (long)shot * a.shot_stride);
+    char *outb = reinterpret_cast<char *>(a.out + (long)shot * out_ss);
 
     // ---- issue every global load up front: they share one memory round trip -------------------
     const int inj_tab = a.inj_per_shot ? shot : 0;
@@ -217,12 +219,14 @@ __global__ __launch_bounds__(TX *TZ / V, V == 2 ? MIFWI_2D_V2_BLOCKS : ((MODE ==
     }
     PV<V> m4 = pv_fill<V>(1.f), e4 = pv_fill<V>(0.f), o4 = e4;
     PV<V> u04 = e4, up4 = e4, gv = e4, iv = e4, po4 = e4;
-    PV<V> bn4 = e4, bc4 = e4, bo4 = e4, bd4 = e4;
+    PV<V> bn4 = e4, bc4 = e4, bo4 = e4, bd4 = e4, pt4 = e4, bh4 = e4;
     const long gs = (long)shot * a.g_shot_stride + p;
     if (live) {
         m4 = pv_ld<V>(reinterpret_cast<const char *>(a.m), pb);
         e4 = pv_ld<V>(reinterpret_cast<const char *>(a.eta), pb);
         o4 = pv_ld<V>(oldb, pb);
+        if (a.pt) pt4 = pv_ld<V>(reinterpret_cast<const char *>(a.pt + (long)shot * a.shot_stride), pb);   // block-uniform
+        if (GRAD && a.bih) bh4 = pv_ld<V>(reinterpret_cast<const char *>(a.bih + (long)shot * a.g_shot_stride), pb);
         if (GRAD) {
             if (a.save_scale) {   // half-precision saved levels (block-uniform branch)
                 const float inv = 1.0f / a.save_scale[shot];
@@ -301,6 +305,23 @@ __global__ __launch_bounds__(TX *TZ / V, V == 2 ? MIFWI_2D_V2_BLOCKS : ((MODE ==
         }
         const float(&mm)[V] = m4.v, (&ee)[V] = e4.v, (&oo)[V] = o4.v;
         float res[V];
+        if (MODE == 0 && a.pre_mode) {   // block-uniform: a field derived from `cur`, not a time step (see Step2DArgs)
+#pragma unroll
+            for (int i = 0; i < V; ++i)
+                res[i] = a.pre_mode == 1 ? uc[i] + fast_div(a.pre_c * lap[i], mm[i])
+                                         : (a.pre_mode == 2 ? fast_div(lap[i], mm[i] * mm[i]) : lap[i]);
+            if (z + V - 1 < a.n2) {
+                pv_st<V>(outb, pb, res);
+            } else {
+                for (int i = 0; i < V; ++i)
+                    if (z + i < a.n2) a.out[ps + i] = res[i];
+            }
+            return;
+        }
+        if (a.pt) {   // the stencilled field was z; the pointwise terms take the level itself
+#pragma unroll
+            for (int i = 0; i < V; ++i) uc[i] = pt4.v[i];
+        }
 #pragma unroll
         for (int i = 0; i < V; ++i) {
             const float ed = ee[i] * a.dt;
@@ -385,6 +406,10 @@ __global__ __launch_bounds__(TX *TZ / V, V == 2 ? MIFWI_2D_V2_BLOCKS : ((MODE ==
                     il[i] = illum_accumulate(illum_accumulate(il[i], up[i]), u0[i]);   // levels nt-1, nt-2
                 else
                     il[i] = illum_accumulate(il[i], u0[i]);
+            }
+            if (a.bih) {   // fourth-order-in-time kernel: the biharmonic term of this step's saved level
+#pragma unroll
+                for (int i = 0; i < V; ++i) g[i] = __builtin_fmaf(-(a.pre_c * bh4.v[i]), uc[i], g[i]);
             }
             if (full) {
                 pv_st<V>(reinterpret_cast<char *>(a.grad + (long)shot * a.g_shot_stride), pb, g);

@@ -180,6 +180,7 @@ static void destroy(Plan *p)
     dev_free(p->d_save_scale);
     dev_free(p->d_t4);
     dev_free(p->d_w2);
+    dev_free(p->d_bih);
     dev_free(p->d_dense);
     dev_free(p->d_partial);
     dev_free(p->d_fval);
@@ -512,7 +513,10 @@ static int create(const mifwi_config *cfg, mifwi_plan **out)
     if (const char *env = getenv("MIFWI_PAIR_GRAD")) p->pair_grad = atoi(env);  // tuning experiments
     if (const char *env = getenv("MIFWI_PAIR_SAVE")) p->pair_save = atoi(env);  // tuning experiments
     if (const char *env = getenv("MIFWI_2D_VEC")) p->vec2d = atoi(env);  // tuning experiments
-    if (cfg->ndim == 2 && cfg->dtype == MIFWI_F32 && !(cfg->flags & (MIFWI_FLAG_GENERIC | MIFWI_FLAG_OT4 | MIFWI_FLAG_PML))) {
+    // the fourth-order-in-time kernel runs on the tiled kernels too (see Step2DArgs::pt), except with
+    // half-precision saved levels (its gradient stencils the saved level)
+    const bool ot4_untiled = (cfg->flags & MIFWI_FLAG_OT4) && ((cfg->flags & MIFWI_FLAG_SAVE_F16) || getenv("MIFWI_OT4_UNTILED"));
+    if (cfg->ndim == 2 && cfg->dtype == MIFWI_F32 && !(cfg->flags & (MIFWI_FLAG_GENERIC | MIFWI_FLAG_PML)) && !ot4_untiled) {
         // tiled fast path: pick the tile shape that wastes fewer threads on this grid
         const int n1 = p->L.n[1], n2 = p->L.n[2];
         auto waste = [&](int tx, int tz) { return (double)((n1 + tx - 1) / tx * tx) * ((n2 + tz - 1) / tz * tz); };
@@ -527,7 +531,7 @@ static int create(const mifwi_config *cfg, mifwi_plan **out)
         if (const char *env = getenv("MIFWI_PERSIST")) p->persist = atoi(env);   // 0: one kernel per step always
         if (const char *env = getenv("MIFWI_PERSIST_SPIN")) p->persist_spin = atoi(env);   // tests: 0 abandons at once
     }
-    if (cfg->ndim == 3 && cfg->dtype == MIFWI_F32 && !(cfg->flags & (MIFWI_FLAG_GENERIC | MIFWI_FLAG_OT4))) {
+    if (cfg->ndim == 3 && cfg->dtype == MIFWI_F32 && !(cfg->flags & MIFWI_FLAG_GENERIC) && !ot4_untiled) {
         // 2.5-D fast path: 16 x 64 tiles of the (y, z) plane, x split into chunks so that one launch
         // offers several blocks per CU
         p->kind = 2;
@@ -540,7 +544,7 @@ static int create(const mifwi_config *cfg, mifwi_plan **out)
         p->bpc_fwd = step3d_blocks_per_cu(p->L.R, false);
         p->bpc_grad = step3d_blocks_per_cu(p->L.R, true);
         if (const char *env = getenv("MIFWI_3D_NCHUNK")) p->nchunk_env = std::max(1, atoi(env));  // tuning experiments
-        if (cfg->flags & MIFWI_FLAG_TIME_BLOCK) p->slab_w = 64, p->slab_chunks = 2;   // the best measured at 592^3
+        if ((cfg->flags & MIFWI_FLAG_TIME_BLOCK) && !(cfg->flags & MIFWI_FLAG_OT4)) p->slab_w = 64, p->slab_chunks = 2;   // the best measured at 592^3
         if (const char *env = getenv("MIFWI_3D_SLAB")) p->slab_w = atoi(env);                      // tuning experiments
         if (const char *env = getenv("MIFWI_3D_SLAB_CHUNKS")) p->slab_chunks = std::max(1, atoi(env));
         if (p->slab_w > 0 && p->slab_w < 2 * p->L.R) p->slab_w = 2 * p->L.R;
@@ -573,6 +577,7 @@ static int create(const mifwi_config *cfg, mifwi_plan **out)
     if (cfg->flags & MIFWI_FLAG_OT4) {
         if ((rc = dev_alloc(*p, &p->d_t4, S * field * es, true))) return bail(rc);
         if ((rc = dev_alloc(*p, &p->d_w2, S * field * es, true))) return bail(rc);
+        if (p->kind != 0 && (rc = dev_alloc(*p, &p->d_bih, S * field * es, true))) return bail(rc);
     }
     if ((rc = dev_alloc(*p, &p->d_wavelet, S * nt * std::max(1, cfg->nsrc) * es, true))) return bail(rc);
     if ((rc = dev_alloc(*p, &p->d_srca, S * nt * std::max(1, cfg->nsrc) * es, true))) return bail(rc);
@@ -900,6 +905,54 @@ struct BornTerm {
     const T *dm;             // haloed, shared by the shots
 };
 
+// ---- fourth-order-in-time kernel on the tiled kernels (operators.py:52-56, 216-219) ---------------
+// Before the step proper, a launch of the same kernel writes z = cur + dt^2/12 laplace(cur)/m into the scratch
+// field d_t4 (one field per shot); the step then stencils z and takes its pointwise terms from the level itself
+// (Step2DArgs::pt).  `base` carries the constants only: a derived field has nothing injected or sampled.
+template <typename Args>
+static void ot4_derive_args(const Plan &p, const Args &base, Args &q, const float *in, long in_stride, float *out, int mode)
+{
+    q = base;
+    q.cur = in, q.old = in, q.out = out;   // `old` is read and not used
+    q.shot_stride = in_stride;
+    q.out_shot_stride = p.L.field;
+    q.pre_mode = mode;
+    q.pre_c = base.dt2 / 12.0f;
+}
+static int ot4_launch(Plan &p, const Step2DArgs &q) { return launch_step2d(p, q, p.stream); }
+static int ot4_launch(Plan &p, const Step3DArgs &q) { return launch_step3d(p, q, p.stream); }
+// z of a.cur; on return a stencils z
+template <typename Args>
+static int ot4_prestep(Plan &p, const Args &base, Args &a, int &launches)
+{
+    if (!(p.cfg.flags & MIFWI_FLAG_OT4)) return MIFWI_OK;
+    Args q;
+    ot4_derive_args(p, base, q, a.cur, a.shot_stride, (float *)p.d_t4, 1);
+    int rc;
+    if ((rc = ot4_launch(p, q))) return rc;
+    launches += 1;
+    a.pt = a.cur;
+    a.cur = (const float *)p.d_t4;
+    a.cur_shot_stride = p.L.field;
+    a.pre_c = q.pre_c;
+    return MIFWI_OK;
+}
+// gradient launches: a.bih = laplace(laplace(u0)/m^2) of the saved forward level u0, through d_w2
+template <typename Args>
+static int ot4_bih(Plan &p, const Args &base, Args &a, const float *u0, long u_stride, int &launches)
+{
+    if (!(p.cfg.flags & MIFWI_FLAG_OT4)) return MIFWI_OK;
+    Args q;
+    int rc;
+    ot4_derive_args(p, base, q, u0, u_stride, (float *)p.d_w2, 2);
+    if ((rc = ot4_launch(p, q))) return rc;
+    ot4_derive_args(p, base, q, (const float *)p.d_w2, p.L.field, (float *)p.d_bih, 3);
+    if ((rc = ot4_launch(p, q))) return rc;
+    launches += 2;
+    a.bih = (const float *)p.d_bih;
+    return MIFWI_OK;
+}
+
 // One forward step: out = step(cur, old) + injected source term of `time`; with `interp` the
 // receivers sample `cur` into d_rec[time].
 template <typename T>
@@ -915,6 +968,7 @@ static int forward_step(Plan &p, const LoopCtx<T> &c, const T *cur, const T *old
         if (inject) set_inject(a, p.src, p);
         if (interp) set_interp(a, p.rec, p.d_rec);
         a.cur = (const float *)cur, a.old = (const float *)old, a.out = (float *)out, a.time = time;
+        if ((rc = ot4_prestep(p, c.a2, a, launches))) return rc;
         a.copy = (float *)copy, a.copy_shot_stride = copy_stride, a.copy_prev = (float *)copy_prev;
         if (copy && p.save_f16) a.save_scale = (const float *)p.d_save_scale;
         if (born) {
@@ -937,6 +991,7 @@ static int forward_step(Plan &p, const LoopCtx<T> &c, const T *cur, const T *old
         if (inject) set_inject3(a, p.src, p);
         if (interp) set_interp3(a, p.rec, p.d_rec);
         a.cur = (const float *)cur, a.old = (const float *)old, a.out = (float *)out, a.time = time;
+        if ((rc = ot4_prestep(p, c.a3, a, launches))) return rc;
         if (copy) {
             if (!p.save_f16) return fail(MIFWI_EINVAL, "internal: the 3-D kernel copies half-precision levels only");
             a.copy16 = copy, a.copy_shot_stride = copy_stride, a.save_scale = (const float *)p.d_save_scale;
@@ -1003,6 +1058,7 @@ static int backward_step(Plan &p, const LoopCtx<T> &c, const T *cur, const T *ol
         if (!with_grad && pair_role != 1) set_interp(a, p.src, p.d_srca);
         a.pair = (pair_role == 2);
         a.cur = (const float *)cur, a.old = (const float *)old, a.out = (float *)out, a.time = time;
+        if ((rc = ot4_prestep(p, c.a2, a, launches))) return rc;
         if (with_grad) {
             a.um = (const float *)um, a.uc = (const float *)u0, a.up = (const float *)up;
             a.u_shot_stride = u_stride;
@@ -1011,6 +1067,7 @@ static int backward_step(Plan &p, const LoopCtx<T> &c, const T *cur, const T *ol
             a.illum = with_illum ? (float *)p.d_illum : nullptr;
             a.g_shot_stride = p.L.field;
             a.first = first;
+            if ((rc = ot4_bih(p, c.a2, a, (const float *)u0, u_stride, launches))) return rc;
         }
         if ((rc = launch_step2d(p, a, p.stream))) return rc;
         launches += 1;
@@ -1023,6 +1080,7 @@ static int backward_step(Plan &p, const LoopCtx<T> &c, const T *cur, const T *ol
         if (!with_grad && pair_role != 1) set_interp3(a, p.src, p.d_srca);
         a.pair = (pair_role == 2);
         a.cur = (const float *)cur, a.old = (const float *)old, a.out = (float *)out, a.time = time;
+        if ((rc = ot4_prestep(p, c.a3, a, launches))) return rc;
         if (with_grad) {
             a.um = (const float *)um, a.uc = (const float *)u0, a.up = (const float *)up;
             a.u_shot_stride = u_stride;
@@ -1031,6 +1089,7 @@ static int backward_step(Plan &p, const LoopCtx<T> &c, const T *cur, const T *ol
             a.illum = with_illum ? (float *)p.d_illum : nullptr;
             a.g_shot_stride = p.L.field;
             a.first = first;
+            if ((rc = ot4_bih(p, c.a3, a, (const float *)u0, u_stride, launches))) return rc;
         }
         if ((rc = launch_step3d(p, a, p.stream))) return rc;
         launches += 1;
@@ -1206,7 +1265,7 @@ static int prepare_save(Plan &p)
 // `sampled`: the point set the loop interpolates (its points must fit one per thread and tile), or null.
 static bool persist_eligible(Plan &p, int nshots, const SparseSet *sampled, bool grad)
 {
-    if (!p.persist || p.kind != 1 || p.esize != 4 || p.save_f16) return false;
+    if (!p.persist || p.kind != 1 || p.esize != 4 || p.save_f16 || (p.cfg.flags & MIFWI_FLAG_OT4)) return false;
     if (p.cfg.flags & (MIFWI_FLAG_ASYNC | MIFWI_FLAG_NO_GRAPH)) return false;
     if (!((p.tile_tx == 32 && p.tile_tz == 32) || (p.tile_tx == 16 && p.tile_tz == 64)) || p.vec2d != 4) return false;
     if (p.cfg.nt < 3) return false;
@@ -1467,7 +1526,7 @@ static int run_backward(Plan &p, int nshots, bool with_grad, bool with_illum)
     // Measured on 592^3 (2.5-D kernel): backward loop at order 8 with half-precision levels 670 -> 608 ms,
     // checkpointed with float levels 1084 -> 1033 ms (recomputation included); fully saved float levels,
     // nt = 200: order 16 291 -> 272 ms, order 4 256 -> 242 ms.
-    const bool pair_grad = with_grad && p.pair_grad && p.kind != 0;
+    const bool pair_grad = with_grad && p.pair_grad && p.kind != 0 && !(p.cfg.flags & MIFWI_FLAG_OT4);
     auto pair_role = [&](int time) {
         if (!pair_grad) return 0;
         if (time % 2 == 0) return (time != nt - 2 && time >= 2) ? 1 : 0;

@@ -130,7 +130,7 @@ struct Plan {
     void *d_res = nullptr;                   // [max_shots][nt][nrec]   adjoint source / residual
     void *d_srca = nullptr;                  // [max_shots][nt][nsrc]
     void *d_grad = nullptr, *d_illum = nullptr; // [max_shots][field] haloed accumulators
-    void *d_t4 = nullptr, *d_w2 = nullptr;   // OT4 scratch fields, [max_shots][field] each
+    void *d_t4 = nullptr, *d_w2 = nullptr, *d_bih = nullptr;   // OT4 scratch fields, [max_shots][field] each
     // TTI state: parameter fields [6][field], field pairs [2][max_shots][3][field] (forward u,v / adjoint p,r),
     // scratch [4][max_shots][field] (wA, wB, gzA, gzB)
     void *tti_par = nullptr, *tti_fwd = nullptr, *tti_adj = nullptr, *tti_tmp = nullptr;
@@ -413,6 +413,20 @@ struct Step2DArgs {
     // out += dt^2 * ( -dm * (b_un - 2 b_uc + b_uo) / dt^2 ) / ( m + eta dt )   (operators.py:263)
     const float *b_un, *b_uc, *b_uo, *b_dm;
     long b_shot_stride;
+    // Fourth-order-in-time kernel (OT4, operators.py:52-56: laplace(u) + dt^2/12 laplace(laplace(u)/m)).  The
+    // Laplacian is linear, so the sum is the Laplacian of z = u + dt^2/12 laplace(u)/m: a launch with pre_mode 1
+    // writes z, and the step proper stencils z (`cur`) while its pointwise terms and the sampled receivers use the
+    // level itself (`pt`, null when `cur` is the level).  pre_mode != 0 launches compute, instead of a time step,
+    // out = 1: cur + pre_c laplace(cur)/m, 2: laplace(cur)/m^2, 3: laplace(cur) (nothing injected or sampled).
+    // `bih` (gradient launches, or null) holds laplace(laplace(u0)/m^2) of the saved level: the gradient gains
+    // -pre_c * bih * v (operators.py:218).
+    const float *pt;
+    int pre_mode;
+    float pre_c;
+    const float *bih;
+    // elements between the shots of `cur` and of `out` when they differ from shot_stride (0: they do not); `old`
+    // and `pt` always use shot_stride
+    long cur_shot_stride, out_shot_stride;
 };
 int launch_step2d(const Plan &p, const Step2DArgs &a, hipStream_t stream);
 
@@ -477,6 +491,12 @@ struct Step3DArgs {
     void *copy16;
     long copy_shot_stride;
     const float *save_scale;
+    // fourth-order-in-time kernel: see Step2DArgs
+    const float *pt;
+    int pre_mode;
+    float pre_c;
+    const float *bih;
+    long cur_shot_stride, out_shot_stride;
 };
 int launch_step3d(const Plan &p, const Step3DArgs &a, hipStream_t stream);
 int launch_eta_zero(const Plan &p, unsigned char *flags, int *free_range);

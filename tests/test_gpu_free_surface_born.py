@@ -173,6 +173,52 @@ def test_3d_ot4(mifwi):
                             kernel='OT4', seed=8))
 
 
+# The float32 OT4 plans run on the tiled kernels: a launch writes z = u + dt^2/12 laplace(u)/m and the step
+# stencils z (flags 0); flags 4 selects the untiled kernels.
+@pytest.mark.parametrize("flags", [0, 4])
+def test_2d_ot4_so16_batch(mifwi, flags):
+    _check_case(mifwi, Case((70, 90), (10.0, 10.0), nbl=12, space_order=16, nt=120, nshots=3, nrec=17,
+                            kernel='OT4', seed=11), flags)
+
+
+def test_3d_ot4_tiles(mifwi):
+    # several tiles in y and z, two shots, order 8
+    _check_case(mifwi, Case((24, 37, 75), (10.0, 10.0, 10.0), nbl=6, space_order=8, nt=40, nshots=2, nrec=9,
+                            kernel='OT4', seed=12), 0)
+
+
+@pytest.mark.parametrize("shape", [(70, 90), (24, 37, 75)])
+def test_ot4_checkpointed_gradient_is_bit_identical(mifwi, shape):
+    """MIFWI_FLAG_CHECKPOINT (8): the recomputed segments run the same launches as the forward pass."""
+    nd = len(shape)
+    case = Case(shape, (10.0,) * nd, nbl=6, space_order=8, nt=61, nshots=2, nrec=9, kernel='OT4', seed=13)
+    out = []
+    for flags in (0, 8):
+        plan = case.plan(mifwi, flags=flags)
+        rec = plan.forward(case.wavelet, save=True)
+        g, il = plan.gradient(rec, want_illum=True)
+        out.append((np.array(rec), np.array(g), np.array(il), plan.stats()))
+        plan.close()
+    assert out[1][3]["ckpt_steps"] > 0 and out[0][3]["ckpt_steps"] == 0
+    assert np.abs(out[0][1]).max() > 0
+    for a, b in zip(out[0][:3], out[1][:3]):
+        assert np.array_equal(a, b)
+
+
+def test_ot4_tiled_born_matches_untiled(mifwi):
+    case = Case((45, 38), (10.0, 12.5), nbl=9, space_order=8, nt=110, nshots=2, nrec=13, kernel='OT4')
+    dm = _dm(case)
+    out = []
+    for flags in (0, 4):
+        plan = case.plan(mifwi, flags=flags)
+        out.append(np.array(plan.born(case.wavelet, dm)))
+        plan.close()
+    assert np.abs(out[1]).max() > 0
+    # the Born tolerance of this file (second time differences of float32 fields)
+    # (the CPU restatement of Born modelling has no OT4 form: the two GPU paths check each other)
+    assert rel_l2(out[0], out[1]) <= 1e-4
+
+
 def test_ot4_stability_and_solver_dt():
     """acoustic_example.py:66-72: tiny grid, no absorbing layer, tn = 20000, OT4: finite records;
     the solver steps with 1.73 x the CFL time step (wavesolver.py:41-46)."""
