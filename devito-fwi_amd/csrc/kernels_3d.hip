@@ -203,9 +203,13 @@ __device__ inline void lds_stv(float *p, const float (&d)[V])
 // MODE 0: plain propagation, 1: gradient, 2: scattered field of Born modelling, 3: plain propagation that
 // also streams a half-precision copy of the new level into the saved array, 4: gradient of two steps
 // (a.pair: the step before ran as MODE 0 and its terms are added here, see Step2DArgs::pair).
-template <int R, int TY, int TZ, int V, int MODE, bool ISO>
-__global__ __launch_bounds__(TY *TZ / V, (MODE == 1 || MODE == 2 || MODE == 4 ? MIFWI_3D_GRAD_WAVES : 3) * (TY * TZ / V) / 256) void step3d_kernel(Step3DArgs a)
+// The fourth-order-in-time kernel (Step2DArgs::pt, pre_mode, bih) has variants of its own, so that the common ones
+// carry none of it: 5 = mode 0, 6 = mode 1, 7 = mode 2 with those arguments honoured.
+template <int R, int TY, int TZ, int V, int XMODE, bool ISO>
+__global__ __launch_bounds__(TY *TZ / V, (XMODE == 1 || XMODE == 2 || XMODE >= 4 ? MIFWI_3D_GRAD_WAVES : 3) * (V == 2 ? 2 : 1)) void step3d_kernel(Step3DArgs a)
 {
+    constexpr bool OT4 = XMODE >= 5;
+    constexpr int MODE = XMODE == 5 ? 0 : (XMODE == 6 ? 1 : (XMODE == 7 ? 2 : XMODE));
     constexpr bool GRAD = (MODE == 1 || MODE == 4), PAIR = (MODE == 4), BORN = (MODE == 2);
     constexpr int NT = TY * TZ / V;                     // threads per block
     constexpr int RZ = (R + 3) / 4 * 4;
@@ -232,7 +236,7 @@ __global__ __launch_bounds__(TY *TZ / V, (MODE == 1 || MODE == 2 || MODE == 4 ? 
         const int tab = a.itp_per_shot ? shot : 0;
         const int32_t *idx = a.pt_idx + ((long)tab * a.itp_npoint + pnt) * 8;
         const float *w = a.pt_w + ((long)tab * a.itp_npoint + pnt) * 8;
-        const float *f = (a.pt ? a.pt : a.cur) + (long)shot * a.shot_stride;
+        const float *f = (OT4 && a.pt ? a.pt : a.cur) + (long)shot * a.shot_stride;
         float sum = 0.f;
 #pragma unroll
         for (int c = 0; c < 8; ++c) sum += w[c] * f[idx[c]];
@@ -267,9 +271,9 @@ __global__ __launch_bounds__(TY *TZ / V, (MODE == 1 || MODE == 2 || MODE == 4 ? 
     const unsigned col_l = live ? col : kDead;            // as a load offset
     const unsigned col_s = (live && full) ? col : kDead;  // as the offset of a V-point store
     const long sb = a.s0 * 4;
-    const char *cur = reinterpret_cast<const char *>(a.cur + (long)shot * (a.cur_shot_stride ? a.cur_shot_stride : a.shot_stride));
+    const char *cur = reinterpret_cast<const char *>(a.cur + (long)shot * (OT4 && a.cur_shot_stride ? a.cur_shot_stride : a.shot_stride));
     const char *old = reinterpret_cast<const char *>(a.old + (long)shot * a.shot_stride);
-    char *out = reinterpret_cast<char *>(a.out + (long)shot * (a.out_shot_stride ? a.out_shot_stride : a.shot_stride));
+    char *out = reinterpret_cast<char *>(a.out + (long)shot * (OT4 && a.out_shot_stride ? a.out_shot_stride : a.shot_stride));
     const char *mb = reinterpret_cast<const char *>(a.m);
     const char *eb = reinterpret_cast<const char *>(a.eta);
     // descriptors: the stencilled level starts R planes early so that plane offsets are never negative
@@ -351,8 +355,8 @@ __global__ __launch_bounds__(TY *TZ / V, (MODE == 1 || MODE == 2 || MODE == 4 ? 
         float ptv[V], bhv[V];
 #pragma unroll
         for (int i = 0; i < V; ++i) ptv[i] = bhv[i] = 0.f;
-        if (a.pt) bldv<V>(buf_of(reinterpret_cast<const char *>(a.pt + (long)shot * a.shot_stride)), (unsigned)x * sbu, col_l, ptv);
-        if (GRAD && a.bih)
+        if (OT4 && a.pt) bldv<V>(buf_of(reinterpret_cast<const char *>(a.pt + (long)shot * a.shot_stride)), (unsigned)x * sbu, col_l, ptv);
+        if (OT4 && GRAD && a.bih)
             bldv<V, kBufStream>(buf_of(reinterpret_cast<const char *>(a.bih + (long)shot * a.g_shot_stride)), (unsigned)x * sbu, col_l, bhv);
 
         // accumulators and saved level(s) of this plane: issued with the coefficient loads, used last
@@ -484,11 +488,11 @@ __global__ __launch_bounds__(TY *TZ / V, (MODE == 1 || MODE == 2 || MODE == 4 ? 
             float lap[V];
 #pragma unroll
             for (int i = 0; i < V; ++i) lap[i] = lap2[i / 2][i % 2];
-            if (a.pt) {   // the stencilled field was z; the pointwise terms take the level itself
+            if (OT4 && a.pt) {   // the stencilled field was z; the pointwise terms take the level itself
 #pragma unroll
                 for (int i = 0; i < V; ++i) uc[i] = ptv[i];
             }
-            if (MODE == 0 && a.pre_mode) {   // block-uniform: a field derived from `cur`, not a time step
+            if (OT4 && MODE == 0 && a.pre_mode) {   // block-uniform: a field derived from `cur`, not a time step
 #pragma unroll
                 for (int i = 0; i < V; ++i)
                     res[i] = a.pre_mode == 1 ? uc[i] + fast_div3(a.pre_c * lap[i], mm[i])
@@ -530,7 +534,7 @@ __global__ __launch_bounds__(TY *TZ / V, (MODE == 1 || MODE == 2 || MODE == 4 ? 
                     else
                         il[i] = illum_accumulate(il[i], u0[i]);
                 }
-                if (a.bih) {
+                if (OT4 && a.bih) {
 #pragma unroll
                     for (int i = 0; i < V; ++i) g[i] = __builtin_fmaf(-(a.pre_c * bhv[i]), uc[i], g[i]);
                 }
@@ -622,34 +626,45 @@ int launch_eta_zero(const Plan &p, unsigned char *flags, int *free_range)
     return MIFWI_OK;
 }
 
-template <int R, int V, bool ISO>
+template <int R, int TY, int V, bool ISO>
 static int launch_r3v(const Plan &p, const Step3DArgs &a, hipStream_t stream)
 {
-    constexpr int NT = 16 * 64 / V;
+    constexpr int NT = TY * 64 / V;
     const int nitp = a.pt_idx ? (((a.itp_npoint + NT - 1) / NT) * a.nshots + 7) / 8 * 8 : 0;
     const int nblocks = (a.nwork + 7) / 8 * 8 + nitp;
-    if (a.um && a.pair)
-        hipLaunchKernelGGL((step3d_kernel<R, 16, 64, V, 4, ISO>), dim3(nblocks), dim3(NT), 0, stream, a);
+    const bool ot4 = a.pt || a.pre_mode || a.bih;
+    if (ot4 && V == 4) {
+        if (a.um)
+            hipLaunchKernelGGL((step3d_kernel<R, TY, 64, 4, 6, ISO>), dim3(nblocks), dim3(NT), 0, stream, a);
+        else if (a.b_un)
+            hipLaunchKernelGGL((step3d_kernel<R, TY, 64, 4, 7, ISO>), dim3(nblocks), dim3(NT), 0, stream, a);
+        else
+            hipLaunchKernelGGL((step3d_kernel<R, TY, 64, 4, 5, ISO>), dim3(nblocks), dim3(NT), 0, stream, a);
+    } else if (ot4) {
+        set_error("the fourth-order-in-time kernel runs with four points per thread");
+        return MIFWI_EINVAL;
+    } else if (a.um && a.pair)
+        hipLaunchKernelGGL((step3d_kernel<R, TY, 64, V, 4, ISO>), dim3(nblocks), dim3(NT), 0, stream, a);
     else if (a.um)
-        hipLaunchKernelGGL((step3d_kernel<R, 16, 64, V, 1, ISO>), dim3(nblocks), dim3(NT), 0, stream, a);
+        hipLaunchKernelGGL((step3d_kernel<R, TY, 64, V, 1, ISO>), dim3(nblocks), dim3(NT), 0, stream, a);
     else if (a.b_un)   // always four points per thread
-        hipLaunchKernelGGL((step3d_kernel<R, 16, 64, 4, 2, ISO>), dim3((a.nwork + 7) / 8 * 8 +
-                               (a.pt_idx ? (((a.itp_npoint + 255) / 256) * a.nshots + 7) / 8 * 8 : 0)),
-                           dim3(256), 0, stream, a);
+        hipLaunchKernelGGL((step3d_kernel<R, TY, 64, 4, 2, ISO>), dim3((a.nwork + 7) / 8 * 8 +
+                               (a.pt_idx ? (((a.itp_npoint + TY * 16 - 1) / (TY * 16)) * a.nshots + 7) / 8 * 8 : 0)),
+                           dim3(TY * 16), 0, stream, a);
     else if (a.copy16)
-        hipLaunchKernelGGL((step3d_kernel<R, 16, 64, V, 3, ISO>), dim3(nblocks), dim3(NT), 0, stream, a);
+        hipLaunchKernelGGL((step3d_kernel<R, TY, 64, V, 3, ISO>), dim3(nblocks), dim3(NT), 0, stream, a);
     else
-        hipLaunchKernelGGL((step3d_kernel<R, 16, 64, V, 0, ISO>), dim3(nblocks), dim3(NT), 0, stream, a);
+        hipLaunchKernelGGL((step3d_kernel<R, TY, 64, V, 0, ISO>), dim3(nblocks), dim3(NT), 0, stream, a);
     MIFWI_HIP(hipGetLastError());
     return MIFWI_OK;
 }
 
-template <int R>
+template <int R, int TY>
 static int occupancy_r3(bool grad)
 {
     int nb = 0;
-    hipError_t e = grad ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, step3d_kernel<R, 16, 64, 4, 1, true>, 256, 0)
-                        : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, step3d_kernel<R, 16, 64, 4, 0, true>, 256, 0);
+    hipError_t e = grad ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, step3d_kernel<R, TY, 64, 4, 1, true>, TY * 16, 0)
+                        : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, step3d_kernel<R, TY, 64, 4, 0, true>, TY * 16, 0);
     if (e != hipSuccess) {
         (void)hipGetLastError();
         return 2;
@@ -661,14 +676,14 @@ static int occupancy_r3(bool grad)
 int step3d_blocks_per_cu(int R, bool grad)
 {
     switch (R) {
-        case 1: return occupancy_r3<1>(grad);
-        case 2: return occupancy_r3<2>(grad);
-        case 3: return occupancy_r3<3>(grad);
-        case 4: return occupancy_r3<4>(grad);
-        case 5: return occupancy_r3<5>(grad);
-        case 6: return occupancy_r3<6>(grad);
-        case 7: return occupancy_r3<7>(grad);
-        default: return occupancy_r3<8>(grad);
+        case 1: return occupancy_r3<1, 16>(grad);
+        case 2: return occupancy_r3<2, 16>(grad);
+        case 3: return occupancy_r3<3, 16>(grad);
+        case 4: return occupancy_r3<4, 16>(grad);
+        case 5: return occupancy_r3<5, 16>(grad);
+        case 6: return occupancy_r3<6, 16>(grad);
+        case 7: return occupancy_r3<7, 16>(grad);
+        default: return occupancy_r3<8, 16>(grad);
     }
 }
 
@@ -681,8 +696,8 @@ static int launch_r3(const Plan &p, const Step3DArgs &a, hipStream_t stream)
     // four points per thread (256 threads) by default; two points per thread (512 threads, twice the
     // waves at half the registers) measured slower at every order and is kept for experiments
     const bool two = (p.vec3d == 2);
-    if (two) return iso ? launch_r3v<R, 2, true>(p, a, stream) : launch_r3v<R, 2, false>(p, a, stream);
-    return iso ? launch_r3v<R, 4, true>(p, a, stream) : launch_r3v<R, 4, false>(p, a, stream);
+    if (two) return iso ? launch_r3v<R, 16, 2, true>(p, a, stream) : launch_r3v<R, 16, 2, false>(p, a, stream);
+    return iso ? launch_r3v<R, 16, 4, true>(p, a, stream) : launch_r3v<R, 16, 4, false>(p, a, stream);
 }
 
 int launch_step3d(const Plan &p, const Step3DArgs &a, hipStream_t stream)

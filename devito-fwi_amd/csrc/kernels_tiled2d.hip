@@ -151,13 +151,17 @@ __device__ inline void pv_lds_ld(const float *p, float (&d)[V])
 // MODE 0: plain propagation, 1: gradient, 2: scattered field of Born modelling, 4: gradient of two steps
 // (a.pair): the step before ran as MODE 0 and its terms are added here, which halves the read-modify-write
 // traffic of the accumulators.  V: points per thread (TX*TZ/V threads per block).
-template <int R, int TX, int TZ, int MODE, int V>
+// The fourth-order-in-time kernel (Step2DArgs::pt, pre_mode, bih) has variants of its own, so that the common ones
+// carry none of it: XMODE 5 = mode 0, 6 = mode 1, 7 = mode 2 with those arguments honoured.
+template <int R, int TX, int TZ, int XMODE, int V>
 // Register budget of the gradient variant: 128 VGPRs, i.e. four blocks per CU (unconstrained it takes
 // 136 and three).  A batch of 8 shots is ~3.1 tiles per CU, so with three resident blocks the last
 // tiles of a launch wait for a free slot: 7.6 -> 6.6 us per step.  The plain variant fits anyway and
 // schedules better without the bound.
-__global__ __launch_bounds__(TX *TZ / V, V == 2 ? MIFWI_2D_V2_BLOCKS : ((MODE == 1 || MODE == 4) ? 4 : 1)) void step2d_kernel(Step2DArgs a)
+__global__ __launch_bounds__(TX *TZ / V, V == 2 ? MIFWI_2D_V2_BLOCKS : ((XMODE == 1 || XMODE == 4) ? 4 : 1)) void step2d_kernel(Step2DArgs a)
 {
+    constexpr bool OT4 = XMODE >= 5;
+    constexpr int MODE = XMODE == 5 ? 0 : (XMODE == 6 ? 1 : (XMODE == 7 ? 2 : XMODE));
     constexpr bool GRAD = (MODE == 1 || MODE == 4), PAIR = (MODE == 4), BORN = (MODE == 2);
     constexpr int RZ = (R + 3) / 4 * 4;          // z halo in LDS, multiple of 4
     constexpr int ROWF4 = (TZ + 2 * RZ) / 4;     // float4 per staged row
@@ -181,7 +185,7 @@ __global__ __launch_bounds__(TX *TZ / V, V == 2 ? MIFWI_2D_V2_BLOCKS : ((MODE ==
         const int tab = a.itp_per_shot ? shot : 0;
         const int4 idx = *reinterpret_cast<const int4 *>(a.pt_idx + ((long)tab * a.itp_npoint + pnt) * 4);
         const float4 w = *reinterpret_cast<const float4 *>(a.pt_w + ((long)tab * a.itp_npoint + pnt) * 4);
-        const float *f = (a.pt ? a.pt : a.cur) + (long)shot * a.shot_stride;
+        const float *f = (OT4 && a.pt ? a.pt : a.cur) + (long)shot * a.shot_stride;
         const float sum = w.x * f[idx.x] + w.y * f[idx.y] + w.z * f[idx.z] + w.w * f[idx.w];
         a.vals_out[((long)shot * a.nt + a.time) * a.itp_npoint + pnt] = sum;
         return;
@@ -196,8 +200,8 @@ __global__ __launch_bounds__(TX *TZ / V, V == 2 ? MIFWI_2D_V2_BLOCKS : ((MODE ==
     const int x = x0 + tx, z = z0 + V * tq;
     const bool live = (x < a.n1) && (z < a.n2);
     const long p = a.off0 + (long)x * a.s1 + z;
-    const long cur_ss = a.cur_shot_stride ? a.cur_shot_stride : a.shot_stride;
-    const long out_ss = a.out_shot_stride ? a.out_shot_stride : a.shot_stride;
+    const long cur_ss = OT4 && a.cur_shot_stride ? a.cur_shot_stride : a.shot_stride;
+    const long out_ss = OT4 && a.out_shot_stride ? a.out_shot_stride : a.shot_stride;
     const long ps = (long)shot * out_ss + p;   // of `out`
     const unsigned pb = ((unsigned)a.off0 + (unsigned)x * (unsigned)a.s1 + (unsigned)z) * 4u;   // byte offset of (x, z)
     const char *curb = reinterpret_cast<const char *>(a.cur + (long)shot * cur_ss);
@@ -225,8 +229,8 @@ __global__ __launch_bounds__(TX *TZ / V, V == 2 ? MIFWI_2D_V2_BLOCKS : ((MODE ==
         m4 = pv_ld<V>(reinterpret_cast<const char *>(a.m), pb);
         e4 = pv_ld<V>(reinterpret_cast<const char *>(a.eta), pb);
         o4 = pv_ld<V>(oldb, pb);
-        if (a.pt) pt4 = pv_ld<V>(reinterpret_cast<const char *>(a.pt + (long)shot * a.shot_stride), pb);   // block-uniform
-        if (GRAD && a.bih) bh4 = pv_ld<V>(reinterpret_cast<const char *>(a.bih + (long)shot * a.g_shot_stride), pb);
+        if (OT4 && a.pt) pt4 = pv_ld<V>(reinterpret_cast<const char *>(a.pt + (long)shot * a.shot_stride), pb);   // block-uniform
+        if (OT4 && GRAD && a.bih) bh4 = pv_ld<V>(reinterpret_cast<const char *>(a.bih + (long)shot * a.g_shot_stride), pb);
         if (GRAD) {
             if (a.save_scale) {   // half-precision saved levels (block-uniform branch)
                 const float inv = 1.0f / a.save_scale[shot];
@@ -305,7 +309,7 @@ __global__ __launch_bounds__(TX *TZ / V, V == 2 ? MIFWI_2D_V2_BLOCKS : ((MODE ==
         }
         const float(&mm)[V] = m4.v, (&ee)[V] = e4.v, (&oo)[V] = o4.v;
         float res[V];
-        if (MODE == 0 && a.pre_mode) {   // block-uniform: a field derived from `cur`, not a time step (see Step2DArgs)
+        if (OT4 && MODE == 0 && a.pre_mode) {   // block-uniform: a field derived from `cur`, not a time step (see Step2DArgs)
 #pragma unroll
             for (int i = 0; i < V; ++i)
                 res[i] = a.pre_mode == 1 ? uc[i] + fast_div(a.pre_c * lap[i], mm[i])
@@ -318,7 +322,7 @@ __global__ __launch_bounds__(TX *TZ / V, V == 2 ? MIFWI_2D_V2_BLOCKS : ((MODE ==
             }
             return;
         }
-        if (a.pt) {   // the stencilled field was z; the pointwise terms take the level itself
+        if (OT4 && a.pt) {   // the stencilled field was z; the pointwise terms take the level itself
 #pragma unroll
             for (int i = 0; i < V; ++i) uc[i] = pt4.v[i];
         }
@@ -407,7 +411,7 @@ __global__ __launch_bounds__(TX *TZ / V, V == 2 ? MIFWI_2D_V2_BLOCKS : ((MODE ==
                 else
                     il[i] = illum_accumulate(il[i], u0[i]);
             }
-            if (a.bih) {   // fourth-order-in-time kernel: the biharmonic term of this step's saved level
+            if (OT4 && a.bih) {   // fourth-order-in-time kernel: the biharmonic term of this step's saved level
 #pragma unroll
                 for (int i = 0; i < V; ++i) g[i] = __builtin_fmaf(-(a.pre_c * bh4.v[i]), uc[i], g[i]);
             }
@@ -430,7 +434,14 @@ static int launch_rtv(const Plan &p, const Step2DArgs &a, hipStream_t stream)
 {
     constexpr int NT = TX * TZ / V;
     const int nblocks = a.ntx * a.ntz * a.nshots + (a.pt_idx ? ((a.itp_npoint + NT - 1) / NT) * a.nshots : 0);
-    if (a.um && a.pair)
+    const bool ot4 = a.pt || a.pre_mode || a.bih;
+    if (ot4 && a.um)
+        hipLaunchKernelGGL((step2d_kernel<R, TX, TZ, 6, V>), dim3(nblocks), dim3(NT), 0, stream, a);
+    else if (ot4 && a.b_un)
+        hipLaunchKernelGGL((step2d_kernel<R, TX, TZ, 7, V>), dim3(nblocks), dim3(NT), 0, stream, a);
+    else if (ot4)
+        hipLaunchKernelGGL((step2d_kernel<R, TX, TZ, 5, V>), dim3(nblocks), dim3(NT), 0, stream, a);
+    else if (a.um && a.pair)
         hipLaunchKernelGGL((step2d_kernel<R, TX, TZ, 4, V>), dim3(nblocks), dim3(NT), 0, stream, a);
     else if (a.um)
         hipLaunchKernelGGL((step2d_kernel<R, TX, TZ, 1, V>), dim3(nblocks), dim3(NT), 0, stream, a);
