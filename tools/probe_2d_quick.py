@@ -7,7 +7,8 @@ import mifwi
 from helpers import Case
 so = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 ns = int(sys.argv[2]) if len(sys.argv) > 2 else 8
-case = Case((340, 140), (25., 25.), nbl=40, space_order=so, nt=int(os.environ.get("PROBE_NT", "600")), nshots=ns, nrec=340, seed=1)
+nxp, nzp = [int(v) for v in os.environ.get("PROBE_SHAPE", "340,140").split(",")]   # physical grid; + 2 * 40 of sponge
+case = Case((nxp, nzp), (25., 25.), nbl=40, space_order=so, nt=int(os.environ.get("PROBE_NT", "600")), nshots=ns, nrec=340, seed=1)
 plan = case.plan(mifwi)
 nsteps = case.nt - 2   # per time step, whatever the number of launches
 out = []
@@ -31,6 +32,6 @@ for _ in range(4):
     plan.adjoint(rec)
     st = plan.stats()
     ad.append(st["bwd_ms"] * 1e3 / nsteps)
-print("%s so=%2d shots=%2d  fwd nosave %.2f us  save %.2f us  grad %.2f us  grad-noillum %.2f us  adjoint %.2f us" %
-      (os.path.basename(os.environ.get("MIFWI_LIB", "libmifwi.so")), so, ns, out[0], out[1], min(g), min(g2), min(ad)),
+print("%s grid %dx%d so=%2d shots=%2d  fwd nosave %.2f us  save %.2f us  grad %.2f us  grad-noillum %.2f us  adjoint %.2f us" %
+      (os.path.basename(os.environ.get("MIFWI_LIB", "libmifwi.so")), nxp + 80, nzp + 80, so, ns, out[0], out[1], min(g), min(g2), min(ad)),
       flush=True)
