@@ -24,6 +24,7 @@ namespace mifwi {
 
 typedef int vi4 __attribute__((ext_vector_type(4)));
 typedef float vf4 __attribute__((ext_vector_type(4)));
+typedef float vf2 __attribute__((ext_vector_type(2)));
 __device__ vf4 raw_buffer_load_f4(vi4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.v4f32");
 __device__ int raw_buffer_load_i1(vi4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.i32");
 __device__ void raw_buffer_store_f4(vf4 v, vi4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.store.v4f32");
@@ -57,7 +58,8 @@ __device__ inline float refined_rcp(float b)
 }
 
 // MODE 0: propagation (forward or backward in time), 1: backward with gradient and illumination sums
-template <int R, int TX, int TZ, int MODE>
+// ISO: equal spacing in x and z (one coefficient set in scalar registers instead of two).
+template <int R, int TX, int TZ, int MODE, bool ISO>
 __global__ __launch_bounds__(256, 4) void persist2d_kernel(Persist2DArgs q)
 {
     constexpr bool GRAD = (MODE == 1);
@@ -292,24 +294,38 @@ __global__ __launch_bounds__(256, 4) void persist2d_kernel(Persist2DArgs q)
 #pragma unroll
                 for (int i = 0; i < V; ++i) f[V * k + i] = t[i];
             }
-            float lap[V], uc[V];
+            // The sums are formed for pairs of neighbouring outputs with packed two-float multiply-adds, one
+            // coefficient per multiply-add (see step3d_kernel): every instruction of this phase is paid for by all
+            // the waves that share a SIMD, in every tile of the shot, once per time step.
+            float uc[V];
+            vf2 lap2[V / 2];
 #pragma unroll
-            for (int i = 0; i < V; ++i) {
-                uc[i] = ucur[i];   // what this thread staged, f[RZ + i]
-                lap[i] = a.c0 * uc[i];
+            for (int i = 0; i < V; ++i) uc[i] = ucur[i];   // what this thread staged, f[RZ + i]
+#pragma unroll
+            for (int p = 0; p < V / 2; ++p) lap2[p] = vf2{a.c0, a.c0} * vf2{uc[2 * p], uc[2 * p + 1]};
+#pragma unroll
+            for (int k = 0; k + 1 < V + 2 * RZ; ++k) {
+                const vf2 pk = vf2{f[k], f[k + 1]};
+#pragma unroll
+                for (int p = 0; p < V / 2; ++p) {
+                    const int d = k - RZ - 2 * p, ad = d < 0 ? -d : d;   // distance of the pair from output pair p
+                    if (ad >= 1 && ad <= R) lap2[p] = __builtin_elementwise_fma(vf2{a.cz[ad], a.cz[ad]}, pk, lap2[p]);
+                }
             }
 #pragma unroll
             for (int k = 1; k <= R; ++k) {
-#pragma unroll
-                for (int i = 0; i < V; ++i) lap[i] += a.cz[k] * (f[RZ + i - k] + f[RZ + i + k]);
-            }
-#pragma unroll
-            for (int k = 1; k <= R; ++k) {
+                const float cxk = ISO ? a.cz[k] : a.cx[k];
                 const vf4 lo = *reinterpret_cast<const vf4 *>(ctr - k * P);
                 const vf4 hi = *reinterpret_cast<const vf4 *>(ctr + k * P);
 #pragma unroll
-                for (int i = 0; i < V; ++i) lap[i] += a.cx[k] * (lo[i] + hi[i]);
+                for (int p = 0; p < V / 2; ++p) {
+                    lap2[p] = __builtin_elementwise_fma(vf2{cxk, cxk}, vf2{lo[2 * p], lo[2 * p + 1]}, lap2[p]);
+                    lap2[p] = __builtin_elementwise_fma(vf2{cxk, cxk}, vf2{hi[2 * p], hi[2 * p + 1]}, lap2[p]);
+                }
             }
+            float lap[V];
+#pragma unroll
+            for (int i = 0; i < V; ++i) lap[i] = lap2[i / 2][i % 2];
 #pragma unroll
             for (int i = 0; i < V; ++i)
                 res[i] = fast_div_r(a.dt2 * lap[i] + 2.0f * mm[i] * uc[i] - mm[i] * uold[i] + ed[i] * uc[i], mm[i] + ed[i],
@@ -389,8 +405,9 @@ template <int R, int TX, int TZ>
 static int occupancy_persist_t(bool grad)
 {
     int nb = 0;
-    hipError_t e = grad ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, persist2d_kernel<R, TX, TZ, 1>, 256, 0)
-                        : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, persist2d_kernel<R, TX, TZ, 0>, 256, 0);
+    // (of the variant with two coefficient sets, which needs no fewer registers than the other)
+    hipError_t e = grad ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, persist2d_kernel<R, TX, TZ, 1, false>, 256, 0)
+                        : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, persist2d_kernel<R, TX, TZ, 0, false>, 256, 0);
     if (e != hipSuccess) {
         (void)hipGetLastError();
         return 0;
@@ -422,10 +439,16 @@ int persist2d_blocks_per_cu(int R, int tile_tz, bool grad)
 template <int R, int TX, int TZ>
 static int launch_prt(const Persist2DArgs &q, bool grad, int nblocks, hipStream_t stream)
 {
-    if (grad)
-        hipLaunchKernelGGL((persist2d_kernel<R, TX, TZ, 1>), dim3(nblocks), dim3(256), 0, stream, q);
+    bool iso = true;
+    for (int k = 1; k <= R; ++k) iso = iso && q.a.cx[k] == q.a.cz[k];
+    if (grad && iso)
+        hipLaunchKernelGGL((persist2d_kernel<R, TX, TZ, 1, true>), dim3(nblocks), dim3(256), 0, stream, q);
+    else if (grad)
+        hipLaunchKernelGGL((persist2d_kernel<R, TX, TZ, 1, false>), dim3(nblocks), dim3(256), 0, stream, q);
+    else if (iso)
+        hipLaunchKernelGGL((persist2d_kernel<R, TX, TZ, 0, true>), dim3(nblocks), dim3(256), 0, stream, q);
     else
-        hipLaunchKernelGGL((persist2d_kernel<R, TX, TZ, 0>), dim3(nblocks), dim3(256), 0, stream, q);
+        hipLaunchKernelGGL((persist2d_kernel<R, TX, TZ, 0, false>), dim3(nblocks), dim3(256), 0, stream, q);
     MIFWI_HIP(hipGetLastError());
     return MIFWI_OK;
 }
