@@ -89,6 +89,7 @@ __global__ __launch_bounds__(256, 4) void persist2d_kernel(Persist2DArgs q)
         s_misc[0] = xcc;
         s_misc[1] = atomicAdd(&q.counter[xcc], 1);
         s_misc[2] = 0;
+        s_misc[3] = 0;   // set by a thread whose wait ran out
     }
     __syncthreads();
     // this launch advances shots shot0 .. shot0 + nshots - 1 (at most 8), one per XCD
@@ -225,6 +226,14 @@ __global__ __launch_bounds__(256, 4) void persist2d_kernel(Persist2DArgs q)
         }
     }
 
+    // the divisor m + eta dt of the update and its refined reciprocal do not change during the loop (the terms of
+    // the numerator keep the order of step2d_kernel: regrouping them moved the Marmousi record by 2e-6 of its norm)
+    float bb[V], rr[V];
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+        bb[i] = mm[i] + ed[i];
+        rr[i] = refined_rcp(bb[i]);
+    }
     for (int s = 0; s < q.nsteps; ++s) {
         const int time = time0 + dir * s;
         const unsigned cur_off = (unsigned)(time % 3) * lvl_bytes;
@@ -255,8 +264,10 @@ __global__ __launch_bounds__(256, 4) void persist2d_kernel(Persist2DArgs q)
                 __builtin_amdgcn_s_sleep(1);
             }
         }
-        fail = __syncthreads_or(fail);   // also orders the zeroing of acc before its scatter
-        if (fail) {
+        // (a flag in LDS and one barrier: the block-wide `or` of the library costs three barriers and a reduction)
+        if (fail) s_misc[3] = 1;
+        __syncthreads();   // also orders the zeroing of acc before its scatter
+        if (s_misc[3]) {
             if (tid == 0) __hip_atomic_store(q.abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             return;
         }
@@ -328,8 +339,7 @@ __global__ __launch_bounds__(256, 4) void persist2d_kernel(Persist2DArgs q)
             for (int i = 0; i < V; ++i) lap[i] = lap2[i / 2][i % 2];
 #pragma unroll
             for (int i = 0; i < V; ++i)
-                res[i] = fast_div_r(a.dt2 * lap[i] + 2.0f * mm[i] * uc[i] - mm[i] * uold[i] + ed[i] * uc[i], mm[i] + ed[i],
-                                    refined_rcp(mm[i] + ed[i]));
+                res[i] = fast_div_r(a.dt2 * lap[i] + 2.0f * mm[i] * uc[i] - mm[i] * uold[i] + ed[i] * uc[i], bb[i], rr[i]);
             if (ninj > 0) {
 #pragma unroll
                 for (int i = 0; i < V; ++i) res[i] += acc[V * tid + i];
