@@ -82,7 +82,7 @@ for name, parts in spec.items():
     if e:
         traffic[name] = e
 # whole-loop launches of the 2-D time loops (one launch = nt - 2 steps of 8 shots): every grid of the kernel
-for name, frag in (("persist2d_kernel", "persist2d_kernel<8, 32, 32, 0>"), ("persist2d_kernel<GRAD>", "persist2d_kernel<8, 32, 32, 1>")):
+for name, frag in (("persist2d_kernel", "persist2d_kernel<8, 32, 32, 0,"), ("persist2d_kernel<GRAD>", "persist2d_kernel<8, 32, 32, 1,")):
     parts = [(k[0], k[1]) for k in dur if frag in k[0]]
     e = entry(parts) if parts else None
     if e:
