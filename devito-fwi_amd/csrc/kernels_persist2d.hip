@@ -274,13 +274,6 @@ __global__ __launch_bounds__(256, 4) void persist2d_kernel(Persist2DArgs q)
             hv[i] = vf4{0.f, 0.f, 0.f, 0.f};
             if (h_ok[i]) hv[i] = raw_buffer_load_f4(rotB, (int)h_glb[i], (int)cur_off, kMissL1);
         }
-        // The saved forward level of this step comes from memory and is needed last.  Loads return in the order of
-        // issue, so it is requested AFTER the halo ring: requested first, it held the ring, which the L2 has ready,
-        // back until it had arrived itself.  (Measured: the gradient step costs 0.6 us more than the adjoint step,
-        // all of it this stream -- without the load 2.07 us; requesting it a step ahead changes nothing, nor does
-        // any cache policy of the load.)
-        vf4 u0 = vf4{0.f, 0.f, 0.f, 0.f};
-        if (GRAD && live) u0 = raw_buffer_load_f4(buf_of(usv + (long)time * usv_l), (int)pb, 0, kStream);
         if (ninj > 0) {
             if (wj_cell >= 0) acc[wj_cell] = wj;
             for (int j = tid + NT; j < ninj; j += NT)   // more owned cells than threads (rare)
@@ -290,6 +283,16 @@ __global__ __launch_bounds__(256, 4) void persist2d_kernel(Persist2DArgs q)
         for (int i = 0; i < NHT; ++i)
             if (tid + i * NT < NH) *reinterpret_cast<vf4 *>(&lds[h_lds[i]]) = hv[i];
         __syncthreads();
+        // The saved forward level of this step comes from memory and is needed last.  It is requested only now, when
+        // the halo ring has arrived: loads return in the order of issue, so requested first (at the top of the step:
+        // 2.71 us per step) it held the ring, which the L2 has ready, back until it had arrived itself, and requested
+        // together with the ring (2.63) it competed with the ring of every tile of the shot for the same burst out
+        // of the L2; here 2.42.  The gradient step still costs 0.5 us more than the adjoint step, all of it this
+        // stream (without the load: 2.07 us); requesting it a step ahead changes nothing -- the wait for the tile
+        // store's acknowledgement at the end of the step covers every older load of the wave -- nor does any cache
+        // policy of the load, nor blocks of their own that pull the levels into the L2 ahead of the tiles (2.8-3.2).
+        vf4 u0 = vf4{0.f, 0.f, 0.f, 0.f};
+        if (GRAD && live) u0 = raw_buffer_load_f4(buf_of(usv + (long)time * usv_l), (int)pb, 0, kStream);
 
         // sampled points of the level being read (stored after this step's level has been published)
         float sampled = 0.f;
