@@ -524,7 +524,7 @@ def main():
                 "profile_avg_launch_us": prof_us,
                 "profile_frac": (g_bytes_loop / max(1, bwd_launches)) / (prof_us * 1e-6) / 1e9 / HBM_PEAK_GBS
                 if prof_us else None,
-                "profile": "profiles/r2_02_bench_kernel_stats.txt: rocprofv3 --kernel-trace of this command with --no-batches, mean over "
+                "profile": "profiles/r2_03_bench_kernel_stats.txt: rocprofv3 --kernel-trace of this command with --no-batches, mean over "
                            "the backward loop's launches (plain and two-step gradient launches weighted by count)",
                 "profile_note": "the tracer slows these ~5 us launches: HIP events around the same loop read 8.7 us "
                                 "per launch under rocprofv3 and 5.6 us without it (profiles/r2_01_bench_line_under_trace.json "
@@ -549,7 +549,13 @@ def main():
                                                 "`achieved` and `frac` above price the step at the 32 B per point "
                                                 "that a kernel per step has to move"},
             "bound_note": "the loop is bound by the neighbour synchronisation of each step (1.6 us per step for the "
-                          "exchange alone, tools/micro/xcdsync.hip), not by HBM"})
+                          "exchange alone, tools/micro/xcdsync.hip), not by HBM",
+            "frac_note": "`frac` can exceed 1: `achieved` prices every step at the 32 algorithmic bytes per point of a "
+                         "kernel per step, while this kernel keeps the model, the two newest levels and the gradient sums "
+                         "on chip for the whole loop and moves 13 (bytes_this_kernel_moves.frac is the fraction of the "
+                         "HBM peak it really uses)",
+            "profile": "profiles/r2_03_bench_kernel_stats.txt: rocprofv3 --kernel-trace of this command with "
+                       "--no-batches, mean over the whole-loop launches of the gradient variant"})
         roofline.pop("profile_note", None)
     roofline_fwd = {"bound": "hbm", "achieved": f_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": f_ach / HBM_PEAK_GBS, "traffic": pmc_traffic(st["fwd_kernel"]), "kernel": st["fwd_kernel"],
