@@ -477,6 +477,310 @@ static int launch_tti_step_r(const Plan &p, const StepConsts<T> &k, const TtiPar
     return MIFWI_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// 3-D float32 TTI step as two marches along x (the arithmetic of tti_gz_kernel + tti_step_kernel).  A 256-thread
+// block owns a 16 x 64 tile of the (y, z) plane and a chunk of planes; a thread owns four consecutive z points of
+// one row and keeps the planes it needs again along x in registers.  The y and z neighbours come straight from
+// memory as aligned 16-byte loads -- rows y +- j, and the neighbouring pieces of the z line -- which neighbouring
+// threads of the block request at the same time: no LDS, no barrier.  Stores cost about twice what loads cost on
+// this part, so the first march stores Gz of the two fields only and the second forms the products with the
+// direction cosines (wx = st cp and wy = st sp, tabulated once per model; wz = ct) at the neighbouring points itself.
+// ------------------------------------------------------------------------------------------------
+typedef float tf4 __attribute__((ext_vector_type(4)));
+__device__ inline tf4 ld4t(const float *p) { return *reinterpret_cast<const tf4 *>(p); }
+
+__global__ __launch_bounds__(256) void tti3d_weights_kernel(const float *st, const float *cp, const float *sp, float *wx,
+                                                            float *wy, long n)
+{
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += 256L * gridDim.x) wx[i] = st[i] * cp[i], wy[i] = st[i] * sp[i];
+}
+
+// First march: Gz of A and of B on the grid extended by p points per dimension (gz: [2][shots][field]).  The tile
+// starts at the left end of the row padding, so every thread's four points are one aligned 16-byte piece; the pieces
+// that lie outside the extended grid are computed from padding and stored, and nothing reads them.
+struct Tti3DGzArgs {
+    const float *A, *B;
+    long ab_stride;
+    float *gz;
+    long gz_stride;            // elements between Gz(A) and Gz(B)
+    const float *wx, *wy, *wz;
+    float a[kMaxR / 2 + 1], ih[3];
+    int n0, n1, n2, e, zl;
+    long s0, s1, off0, field;
+    int nty, ntz, nchunk, xchunk, nshots;
+};
+
+template <int P>
+__global__ __launch_bounds__(256) void tti3d_gz_kernel(Tti3DGzArgs a)
+{
+    constexpr int TY = 16, TZ = 64, V = 4;
+    int t = blockIdx.x;
+    const int tile_z = t % a.ntz;
+    t /= a.ntz;
+    const int tile_y = t % a.nty;
+    t /= a.nty;
+    const int chunk = t % a.nchunk;
+    const int shot = t / a.nchunk;
+    const int xa = -a.e + chunk * a.xchunk, xb = min(a.n0 + a.e, xa + a.xchunk);
+    const int tid = threadIdx.x;
+    const int y = -a.e + tile_y * TY + tid / (TZ / V), z = -a.zl + tile_z * TZ + V * (tid % (TZ / V));
+    if (y >= a.n1 + a.e || z >= a.n2 + a.e || xa >= xb) return;
+    const long col = a.off0 + (long)y * a.s1 + z;
+    const float *A = a.A + (long)shot * a.ab_stride + col, *B = a.B + (long)shot * a.ab_stride + col;
+    float *o = a.gz + (long)shot * a.field + col;
+
+    tf4 qa[2 * P + 1], qb[2 * P + 1];   // planes x - P .. x + P (after the shift)
+#pragma unroll
+    for (int j = 0; j < 2 * P; ++j) qa[j + 1] = ld4t(A + (long)(xa - P + j) * a.s0), qb[j + 1] = ld4t(B + (long)(xa - P + j) * a.s0);
+    for (int x = xa; x < xb; ++x) {
+        const long px = (long)x * a.s0;
+#pragma unroll
+        for (int j = 0; j < 2 * P; ++j) qa[j] = qa[j + 1], qb[j] = qb[j + 1];
+        qa[2 * P] = ld4t(A + px + (long)P * a.s0), qb[2 * P] = ld4t(B + px + (long)P * a.s0);
+        const tf4 wx = ld4t(a.wx + col + px), wy = ld4t(a.wy + col + px), wz = ld4t(a.wz + col + px);
+        tf4 dxa = {0.f, 0.f, 0.f, 0.f}, dxb = dxa, dya = dxa, dyb = dxa, dza = dxa, dzb = dxa;
+#pragma unroll
+        for (int j = 1; j <= P; ++j) {
+            dxa += a.a[j] * (qa[P + j] - qa[P - j]);
+            dxb += a.a[j] * (qb[P + j] - qb[P - j]);
+            dya += a.a[j] * (ld4t(A + px + (long)j * a.s1) - ld4t(A + px - (long)j * a.s1));
+            dyb += a.a[j] * (ld4t(B + px + (long)j * a.s1) - ld4t(B + px - (long)j * a.s1));
+        }
+        {
+            float la[V + 8], lb[V + 8];   // z - 4 .. z + 7
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const tf4 va = c == 1 ? qa[P] : ld4t(A + px + 4 * (c - 1)), vb = c == 1 ? qb[P] : ld4t(B + px + 4 * (c - 1));
+#pragma unroll
+                for (int i = 0; i < V; ++i) la[4 * c + i] = va[i], lb[4 * c + i] = vb[i];
+            }
+#pragma unroll
+            for (int j = 1; j <= P; ++j)
+#pragma unroll
+                for (int i = 0; i < V; ++i) {
+                    dza[i] += a.a[j] * (la[4 + i + j] - la[4 + i - j]);
+                    dzb[i] += a.a[j] * (lb[4 + i + j] - lb[4 + i - j]);
+                }
+        }
+        *reinterpret_cast<tf4 *>(o + px) = -(wx * (dxa * a.ih[0]) + wy * (dya * a.ih[1]) + wz * (dza * a.ih[2]));
+        *reinterpret_cast<tf4 *>(o + px + a.gz_stride) = -(wx * (dxb * a.ih[0]) + wy * (dyb * a.ih[1]) + wz * (dzb * a.ih[2]));
+    }
+}
+
+// Second march: X = laplace(A) - Gzz(A), Y = Gzz(B) and the update of both fields.  Registers hold the planes
+// x - R .. x + R of A and the planes x - p .. x + p of the x products wx Gz of both fields.
+struct Tti3DArgs {
+    const float *A;            // stencilled field of shot 0 (forward: u; adjoint: et p + dl r)
+    long a_stride;
+    const float *gz;           // [2][shots][field]
+    long gz_stride;
+    const float *wx, *wy, *wz;
+    const float *et, *dl, *m, *eta;
+    const float *ucur, *uold, *vcur, *vold;
+    float *uout, *vout;
+    long lv_stride;
+    float c0, cx[kMaxR + 1], cy[kMaxR + 1], cz[kMaxR + 1];
+    float a1[kMaxR / 2 + 1], ih[3];
+    float dt, dt2;
+    int n0, n1, n2;
+    long s0, s1, off0, field;
+    int nty, ntz, nchunk, xchunk, nshots, fwd;
+};
+
+template <int R>
+__global__ __launch_bounds__(256) void tti3d_step_kernel(Tti3DArgs a)
+{
+    constexpr int P = R / 2, TY = 16, TZ = 64, V = 4;
+    constexpr int NZ4 = (R + 3) / 4;   // 16-byte pieces of the z line of A on either side
+    int t = blockIdx.x;
+    const int tile_z = t % a.ntz;
+    t /= a.ntz;
+    const int tile_y = t % a.nty;
+    t /= a.nty;
+    const int chunk = t % a.nchunk;
+    const int shot = t / a.nchunk;
+    const int xa = chunk * a.xchunk, xb = min(a.n0, xa + a.xchunk);
+    const int tid = threadIdx.x;
+    const int y = tile_y * TY + tid / (TZ / V), z = tile_z * TZ + V * (tid % (TZ / V));
+    if (y >= a.n1 || z >= a.n2 || xa >= xb) return;
+    const long col = a.off0 + (long)y * a.s1 + z;   // element offset of (plane 0, y, z) in a level
+    const float *A = a.A + (long)shot * a.a_stride + col;
+    const float *gA = a.gz + (long)shot * a.field + col, *gB = gA + a.gz_stride;
+    const float *wx = a.wx + col, *wy = a.wy + col, *wz = a.wz + col;
+    const long lv = (long)shot * a.lv_stride + col;
+
+    tf4 qa[2 * R + 1], qxa[2 * P + 1], qxb[2 * P + 1];
+#pragma unroll
+    for (int j = 0; j < 2 * R; ++j) qa[j + 1] = ld4t(A + (long)(xa - R + j) * a.s0);
+#pragma unroll
+    for (int j = 0; j < 2 * P; ++j) {
+        const long o = (long)(xa - P + j) * a.s0;
+        const tf4 w = ld4t(wx + o);
+        qxa[j + 1] = w * ld4t(gA + o), qxb[j + 1] = w * ld4t(gB + o);
+    }
+    for (int x = xa; x < xb; ++x) {
+        const long px = (long)x * a.s0;
+#pragma unroll
+        for (int j = 0; j < 2 * R; ++j) qa[j] = qa[j + 1];
+        qa[2 * R] = ld4t(A + px + (long)R * a.s0);
+#pragma unroll
+        for (int j = 0; j < 2 * P; ++j) qxa[j] = qxa[j + 1], qxb[j] = qxb[j + 1];
+        {
+            const long o = px + (long)P * a.s0;
+            const tf4 w = ld4t(wx + o);
+            qxa[2 * P] = w * ld4t(gA + o), qxb[2 * P] = w * ld4t(gB + o);
+        }
+        // pointwise streams of this plane
+        const tf4 et = ld4t(a.et + col + px), dl = ld4t(a.dl + col + px), mm = ld4t(a.m + col + px), ee = ld4t(a.eta + col + px);
+        const tf4 uc = ld4t(a.ucur + lv + px), uo = ld4t(a.uold + lv + px), vc = ld4t(a.vcur + lv + px), vo = ld4t(a.vold + lv + px);
+
+        // Laplacian of A: z line and y rows from memory, x from the queue
+        const tf4 ac = qa[R];
+        tf4 lap = a.c0 * ac;
+        {
+            float line[V + 8 * NZ4];
+#pragma unroll
+            for (int c = 0; c < 2 * NZ4 + 1; ++c) {
+                const tf4 v = c == NZ4 ? ac : ld4t(A + px + 4 * (c - NZ4));
+#pragma unroll
+                for (int i = 0; i < V; ++i) line[4 * c + i] = v[i];
+            }
+#pragma unroll
+            for (int k = 1; k <= R; ++k)
+#pragma unroll
+                for (int i = 0; i < V; ++i) lap[i] += a.cz[k] * (line[4 * NZ4 + i - k] + line[4 * NZ4 + i + k]);
+        }
+#pragma unroll
+        for (int k = 1; k <= R; ++k) lap += a.cy[k] * (ld4t(A + px - (long)k * a.s1) + ld4t(A + px + (long)k * a.s1));
+#pragma unroll
+        for (int k = 1; k <= R; ++k) lap += a.cx[k] * (qa[R - k] + qa[R + k]);
+
+        // Gzz of both fields: products along z from three pieces of the line, along x from the queues, along y from rows
+        float za[V + 8], zb[V + 8];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const tf4 w = ld4t(wz + px + 4 * (c - 1));
+            const tf4 va = w * ld4t(gA + px + 4 * (c - 1)), vb = w * ld4t(gB + px + 4 * (c - 1));
+#pragma unroll
+            for (int i = 0; i < V; ++i) za[4 * c + i] = va[i], zb[4 * c + i] = vb[i];
+        }
+        tf4 sA = {0.f, 0.f, 0.f, 0.f}, sB = sA;
+#pragma unroll
+        for (int j = 1; j <= P; ++j) {
+            tf4 tA, tB;
+#pragma unroll
+            for (int i = 0; i < V; ++i) {
+                tA[i] = a.a1[j] * (za[4 + i + j] - za[4 + i - j]) * a.ih[2];
+                tB[i] = a.a1[j] * (zb[4 + i + j] - zb[4 + i - j]) * a.ih[2];
+            }
+            tA += a.a1[j] * (qxa[P + j] - qxa[P - j]) * a.ih[0];
+            tB += a.a1[j] * (qxb[P + j] - qxb[P - j]) * a.ih[0];
+            const long jy = (long)j * a.s1;
+            const tf4 wp = ld4t(wy + px + jy), wm = ld4t(wy + px - jy);
+            tA += a.a1[j] * (wp * ld4t(gA + px + jy) - wm * ld4t(gA + px - jy)) * a.ih[1];
+            tB += a.a1[j] * (wp * ld4t(gB + px + jy) - wm * ld4t(gB + px - jy)) * a.ih[1];
+            sA += tA, sB += tB;
+        }
+        const tf4 X = lap + sA, Y = -sB;   // Gzz = -s
+        const tf4 H0 = a.fwd ? et * X + dl * Y : X;
+        const tf4 Hz = a.fwd ? dl * X + Y : Y;
+        tf4 un, vn;
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+            const float ed = ee[i] * a.dt;
+            un[i] = (a.dt2 * H0[i] + 2.0f * mm[i] * uc[i] - mm[i] * uo[i] + ed * uc[i]) / (mm[i] + ed);
+            vn[i] = (a.dt2 * Hz[i] + 2.0f * mm[i] * vc[i] - mm[i] * vo[i] + ed * vc[i]) / (mm[i] + ed);
+        }
+        if (z + V - 1 < a.n2) {
+            *reinterpret_cast<tf4 *>(a.uout + lv + px) = un;
+            *reinterpret_cast<tf4 *>(a.vout + lv + px) = vn;
+        } else {
+            for (int i = 0; i < V; ++i)
+                if (z + i < a.n2) a.uout[lv + px + i] = un[i], a.vout[lv + px + i] = vn[i];
+        }
+    }
+}
+
+// float32 3-D plans that could allocate the tables of the marches (p.tti_gz3, p.tti_w) take them
+static bool tti3d_available(const Plan &p)
+{
+    return p.L.ndim == 3 && p.esize == 4 && p.tti_gz3 && p.tti_w && !(p.cfg.flags & MIFWI_FLAG_GENERIC) &&
+           p.L.R % 2 == 0 && p.L.R <= 8;
+}
+
+// wx, wy of the parameter fields of the plan (order in p.tti_par: et, dl, ct, st, cp, sp)
+int launch_tti3d_weights(const Plan &p)
+{
+    float *w = (float *)p.tti_w;
+    const float *par = (const float *)p.tti_par;
+    const long f = p.L.field;
+    hipLaunchKernelGGL(tti3d_weights_kernel, dim3(2048), dim3(256), 0, p.stream, par + 3 * f, par + 4 * f, par + 5 * f, w, w + f, f);
+    MIFWI_HIP(hipGetLastError());
+    return MIFWI_OK;
+}
+
+// chunks of planes per tile: about `rounds` blocks per CU, chunks no shorter than twice the planes a chunk primes
+static void tti3d_chunks(const Plan &p, int tiles, int planes, int prime, int rounds, int &nchunk, int &xchunk)
+{
+    int n = (rounds * p.ncu + tiles - 1) / tiles;
+    n = std::max(1, std::min(n, planes / (2 * prime)));
+    xchunk = (planes + n - 1) / n;
+    nchunk = (planes + xchunk - 1) / xchunk;
+}
+
+static int launch_tti3d(const Plan &p, const StepConsts<float> &k, const TtiParams<float> &q, int fwd, const float *A,
+                        const float *B, long ab_stride, const TtiLevels<float> &lv, int nshots, int &launches)
+{
+    float *gz = (float *)p.tti_gz3;
+    const float *w = (const float *)p.tti_w;
+    const long gstride = (long)p.cfg.max_shots * k.field;
+    {
+        Tti3DGzArgs g{};
+        g.A = A, g.B = B, g.ab_stride = ab_stride, g.gz = gz, g.gz_stride = gstride;
+        g.wx = w, g.wy = w + k.field, g.wz = q.ct;
+        for (int j = 1; j <= q.p; ++j) g.a[j] = q.a[j];
+        g.ih[0] = q.ih[0], g.ih[1] = q.ih[1], g.ih[2] = q.ih[2];
+        g.n0 = k.n0, g.n1 = k.n1, g.n2 = k.n2, g.e = q.p, g.zl = p.L.zl;
+        g.s0 = k.s0, g.s1 = k.s1, g.off0 = k.off0, g.field = k.field;
+        g.nty = (k.n1 + 2 * q.p + 15) / 16, g.ntz = (p.L.zl + k.n2 + q.p + 63) / 64;
+        tti3d_chunks(p, g.nty * g.ntz * nshots, k.n0 + 2 * q.p, 2 * q.p, 8, g.nchunk, g.xchunk);
+        g.nshots = nshots;
+        const int nb = g.nty * g.ntz * g.nchunk * nshots;
+        switch (q.p) {
+            case 1: hipLaunchKernelGGL((tti3d_gz_kernel<1>), dim3(nb), dim3(256), 0, p.stream, g); break;
+            case 2: hipLaunchKernelGGL((tti3d_gz_kernel<2>), dim3(nb), dim3(256), 0, p.stream, g); break;
+            case 3: hipLaunchKernelGGL((tti3d_gz_kernel<3>), dim3(nb), dim3(256), 0, p.stream, g); break;
+            default: hipLaunchKernelGGL((tti3d_gz_kernel<4>), dim3(nb), dim3(256), 0, p.stream, g);
+        }
+        MIFWI_HIP(hipGetLastError());
+    }
+    Tti3DArgs a{};
+    a.A = A, a.a_stride = ab_stride, a.gz = gz, a.gz_stride = gstride;
+    a.wx = w, a.wy = w + k.field, a.wz = q.ct;
+    a.et = q.et, a.dl = q.dl, a.m = (const float *)p.m, a.eta = (const float *)p.eta;
+    a.ucur = lv.ucur, a.uold = lv.uold, a.vcur = lv.vcur, a.vold = lv.vold, a.uout = lv.uout, a.vout = lv.vout;
+    a.lv_stride = lv.shot_stride;
+    a.c0 = k.c0;
+    for (int j = 0; j <= p.L.R; ++j) a.cx[j] = k.c[0][j], a.cy[j] = k.c[1][j], a.cz[j] = k.c[2][j];
+    for (int j = 1; j <= q.p; ++j) a.a1[j] = q.a[j];
+    a.ih[0] = q.ih[0], a.ih[1] = q.ih[1], a.ih[2] = q.ih[2];
+    a.dt = k.dt, a.dt2 = k.dt2;
+    a.n0 = k.n0, a.n1 = k.n1, a.n2 = k.n2, a.s0 = k.s0, a.s1 = k.s1, a.off0 = k.off0, a.field = k.field;
+    a.nty = (k.n1 + 15) / 16, a.ntz = (k.n2 + 63) / 64;
+    tti3d_chunks(p, a.nty * a.ntz * nshots, k.n0, 2 * p.L.R, 8, a.nchunk, a.xchunk);
+    a.nshots = nshots, a.fwd = fwd;
+    const int nb = a.nty * a.ntz * a.nchunk * nshots;
+    switch (p.L.R) {
+        case 2: hipLaunchKernelGGL((tti3d_step_kernel<2>), dim3(nb), dim3(256), 0, p.stream, a); break;
+        case 4: hipLaunchKernelGGL((tti3d_step_kernel<4>), dim3(nb), dim3(256), 0, p.stream, a); break;
+        case 6: hipLaunchKernelGGL((tti3d_step_kernel<6>), dim3(nb), dim3(256), 0, p.stream, a); break;
+        default: hipLaunchKernelGGL((tti3d_step_kernel<8>), dim3(nb), dim3(256), 0, p.stream, a);
+    }
+    MIFWI_HIP(hipGetLastError());
+    launches += 2;
+    return MIFWI_OK;
+}
+
 // One TTI time step without the sparse terms.  fwd: A, B = current u, v.  adjoint: A, B are formed
 // into wA, wB first.  Launch count is added to `launches`.
 template <typename T>
@@ -503,6 +807,9 @@ int launch_tti_step(const Plan &p, const StepConsts<T> &k, const TtiParams<T> &q
         hipLaunchKernelGGL((tti_combine_kernel<T>), grid, block, 0, p.stream, k, q, lv.ucur, lv.vcur, lv.shot_stride, wA, wB);
         A = wA, B = wB, ab_stride = k.field;
         launches += 1;
+    }
+    if constexpr (std::is_same<T, float>::value) {
+        if (tti3d_available(p)) return launch_tti3d(p, k, q, fwd, A, B, ab_stride, lv, nshots, launches);
     }
     dim3 gridz((k.n2 + 2 * e + 63) / 64, (k.n1 + 2 * e + 3) / 4, (unsigned)(nshots * (k.n0 + 2 * e0)));
     if (p.L.ndim == 3)

@@ -171,6 +171,8 @@ static void destroy(Plan *p)
     dev_free(p->d_psync);
     if (p->h_abort) (void)hipHostFree(p->h_abort);
     dev_free(p->tti_par);
+    dev_free(p->tti_gz3);
+    dev_free(p->tti_w);
     dev_free(p->tti_fwd);
     dev_free(p->tti_adj);
     dev_free(p->tti_tmp);
@@ -1911,6 +1913,14 @@ static int tti_set_model(Plan &p, const void *eps, const void *delta, const void
         if ((rc = dev_alloc(p, &p.tti_fwd, 2 * S * 3 * fb, true))) return rc;
         if ((rc = dev_alloc(p, &p.tti_adj, 2 * S * 3 * fb, true))) return rc;
         if ((rc = dev_alloc(p, &p.tti_tmp, 4 * S * fb, true))) return rc;
+        // float32 3-D plans step with the two marching kernels when their tables fit beside everything else
+        if (p.L.ndim == 3 && sizeof(T) == 4 && !(p.cfg.flags & MIFWI_FLAG_GENERIC) && !getenv("MIFWI_TTI3D_UNTILED")) {
+            size_t free_b = 0, total_b = 0;
+            if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && (2 * S + 2) * fb < free_b / 2) {
+                if ((rc = dev_alloc(p, &p.tti_gz3, 2 * S * fb, true))) return rc;
+                if ((rc = dev_alloc(p, &p.tti_w, 2 * fb, true))) return rc;
+            }
+        }
     }
     const StepConsts<T> k = make_consts<T>(p);
     T *par = (T *)p.tti_par;
@@ -1927,6 +1937,7 @@ static int tti_set_model(Plan &p, const void *eps, const void *delta, const void
         }
         if ((rc = launch_tti_param<T>(p, k, src, par + (long)f * p.L.field, spec[f].mode, spec[f].halo))) return rc;
     }
+    if (p.tti_w && (rc = launch_tti3d_weights(p))) return rc;
     if (p.tti_ck_K > 0) p.tti_save_valid = false;   // checkpoints belong to the parameters they were taken with
     return finish(p);   // wavefields of earlier runs stay readable: they are not touched here
 }

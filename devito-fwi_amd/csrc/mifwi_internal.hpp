@@ -134,6 +134,9 @@ struct Plan {
     // TTI state: parameter fields [6][field], field pairs [2][max_shots][3][field] (forward u,v / adjoint p,r),
     // scratch [4][max_shots][field] (wA, wB, gzA, gzB)
     void *tti_par = nullptr, *tti_fwd = nullptr, *tti_adj = nullptr, *tti_tmp = nullptr;
+    // 3-D float32 plans: Gz of the two stencilled fields, [2][max_shots][field], and the tables st cp, st sp, [2][field]
+    // (kernels_tti.hip::tti3d_gz_kernel / tti3d_step_kernel)
+    void *tti_gz3 = nullptr, *tti_w = nullptr;
     bool tti_fwd_valid = false, tti_adj_valid = false;
     // host copies of the coordinates last given to mifwi_set_geometry (the sparse tables depend on the tile
     // shape, which the first mifwi_tti_set_model may change)
@@ -324,6 +327,7 @@ struct TtiLevels {
 // (mode 1: 1+2x, 2: sqrt(1+2x), 3: cos, 4: sin); dense == null leaves the constant
 template <typename T>
 int launch_tti_param(const Plan &p, const StepConsts<T> &k, const T *dense, T *haloed, int mode, T halo_value);
+int launch_tti3d_weights(const Plan &p);   // fills p.tti_w from p.tti_par (3-D float32 plans)
 // Optional extra term of a TTI step.  Born (b_un != null): the stepped fields are the scattered ones and get
 // dt^2 * ( -dm * u0.dt2 ) / ( m + eta dt ) resp. the same with v0 (seismic/tti/operators.py:573-576);
 // b_* are the background levels t+1, t, t-1 of shot 0.  Gradient (grad != null): the stepped fields are the
