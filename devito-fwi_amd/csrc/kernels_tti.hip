@@ -487,7 +487,32 @@ static int launch_tti_step_r(const Plan &p, const StepConsts<T> &k, const TtiPar
 // direction cosines (wx = st cp and wy = st sp, tabulated once per model; wz = ct) at the neighbouring points itself.
 // ------------------------------------------------------------------------------------------------
 typedef float tf4 __attribute__((ext_vector_type(4)));
-__device__ inline tf4 ld4t(const float *p) { return *reinterpret_cast<const tf4 *>(p); }
+
+// The loads of the two marches are issued by hand, in batches, each followed by one wait: left to the compiler's
+// scheduler (which, short of registers, moves every load down to its first use) the loop made some twenty round trips
+// to memory per plane.  gld issues a 16-byte load at sbase (uniform) + voff bytes + OFF; vm_wait<N> waits until at
+// most N of the loads issued since are outstanding (loads return in order); arrived() marks a register as written
+// at that point, so that nothing that reads it is moved above the wait.
+template <int OFF>
+__device__ inline void gld(tf4 &v, unsigned voff, const float *sbase)
+{
+    asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(v) : "v"(voff), "s"(sbase), "n"(OFF) : "memory");
+}
+template <int N>
+__device__ inline void vm_wait()
+{
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+__device__ inline void arrived(tf4 &v) { asm volatile("" : "+v"(v)); }
+
+// Workgroups go to the eight XCDs in turn and every XCD has an L2 of its own.  Tiles that are neighbours read each
+// other's edge rows and edge cache lines, so an XCD is given a contiguous run of the tile order: block b is the
+// (b / 8)-th block of XCD b % 8.
+__device__ inline int xcd_contiguous_block()
+{
+    const int nb = gridDim.x, b = blockIdx.x, xcd = b & 7, q = nb >> 3, r = nb & 7;
+    return xcd * q + min(xcd, r) + (b >> 3);
+}
 
 __global__ __launch_bounds__(256) void tti3d_weights_kernel(const float *st, const float *cp, const float *sp, float *wx,
                                                             float *wy, long n)
@@ -514,7 +539,7 @@ template <int P>
 __global__ __launch_bounds__(256) void tti3d_gz_kernel(Tti3DGzArgs a)
 {
     constexpr int TY = 16, TZ = 64, V = 4;
-    int t = blockIdx.x;
+    int t = xcd_contiguous_block();
     const int tile_z = t % a.ntz;
     t /= a.ntz;
     const int tile_y = t % a.nty;
@@ -523,36 +548,64 @@ __global__ __launch_bounds__(256) void tti3d_gz_kernel(Tti3DGzArgs a)
     const int shot = t / a.nchunk;
     const int xa = -a.e + chunk * a.xchunk, xb = min(a.n0 + a.e, xa + a.xchunk);
     const int tid = threadIdx.x;
-    const int y = -a.e + tile_y * TY + tid / (TZ / V), z = -a.zl + tile_z * TZ + V * (tid % (TZ / V));
-    if (y >= a.n1 + a.e || z >= a.n2 + a.e || xa >= xb) return;
-    const long col = a.off0 + (long)y * a.s1 + z;
-    const float *A = a.A + (long)shot * a.ab_stride + col, *B = a.B + (long)shot * a.ab_stride + col;
-    float *o = a.gz + (long)shot * a.field + col;
+    const int yy = tile_y * TY + tid / (TZ / V), zz = tile_z * TZ + V * (tid % (TZ / V));   // from (-e, -zl)
+    if (yy >= a.n1 + 2 * a.e || zz >= a.n2 + a.e + a.zl || xa >= xb) return;
+    const unsigned voff = (unsigned)((long)yy * a.s1 + zz) * 4u;   // bytes from the first point of the extended plane
+    const long org = a.off0 - (long)a.e * a.s1 - a.zl;             // that point, in plane 0
+    const float *A = a.A + (long)shot * a.ab_stride + org, *B = a.B + (long)shot * a.ab_stride + org;
+    float *o = a.gz + (long)shot * a.field + org + voff / 4;
 
     tf4 qa[2 * P + 1], qb[2 * P + 1];   // planes x - P .. x + P (after the shift)
 #pragma unroll
-    for (int j = 0; j < 2 * P; ++j) qa[j + 1] = ld4t(A + (long)(xa - P + j) * a.s0), qb[j + 1] = ld4t(B + (long)(xa - P + j) * a.s0);
+    for (int j = 0; j < 2 * P; ++j) {
+        gld<0>(qa[j + 1], voff, A + (long)(xa - P + j) * a.s0);
+        gld<0>(qb[j + 1], voff, B + (long)(xa - P + j) * a.s0);
+    }
+    vm_wait<0>();
+#pragma unroll
+    for (int j = 1; j <= 2 * P; ++j) arrived(qa[j]), arrived(qb[j]);
     for (int x = xa; x < xb; ++x) {
         const long px = (long)x * a.s0;
+        const float *Ap = A + px, *Bp = B + px;
+        tf4 na, nb, wx, wy, wz, ya[2 * P], yb[2 * P], za[2], zb[2];
+        gld<0>(na, voff, Ap + (long)P * a.s0);
+        gld<0>(nb, voff, Bp + (long)P * a.s0);
+#pragma unroll
+        for (int j = 1; j <= P; ++j) {
+            gld<0>(ya[2 * j - 2], voff, Ap - (long)j * a.s1);
+            gld<0>(ya[2 * j - 1], voff, Ap + (long)j * a.s1);
+            gld<0>(yb[2 * j - 2], voff, Bp - (long)j * a.s1);
+            gld<0>(yb[2 * j - 1], voff, Bp + (long)j * a.s1);
+        }
+        gld<-16>(za[0], voff, Ap);
+        gld<16>(za[1], voff, Ap);
+        gld<-16>(zb[0], voff, Bp);
+        gld<16>(zb[1], voff, Bp);
+        gld<0>(wx, voff, a.wx + org + px);
+        gld<0>(wy, voff, a.wy + org + px);
+        gld<0>(wz, voff, a.wz + org + px);
+        vm_wait<0>();
 #pragma unroll
         for (int j = 0; j < 2 * P; ++j) qa[j] = qa[j + 1], qb[j] = qb[j + 1];
-        qa[2 * P] = ld4t(A + px + (long)P * a.s0), qb[2 * P] = ld4t(B + px + (long)P * a.s0);
-        const tf4 wx = ld4t(a.wx + col + px), wy = ld4t(a.wy + col + px), wz = ld4t(a.wz + col + px);
+#pragma unroll
+        for (int j = 0; j < 2 * P; ++j) arrived(ya[j]), arrived(yb[j]);
+        arrived(na), arrived(nb), arrived(za[0]), arrived(za[1]), arrived(zb[0]), arrived(zb[1]);
+        arrived(wx), arrived(wy), arrived(wz);
+        qa[2 * P] = na, qb[2 * P] = nb;
         tf4 dxa = {0.f, 0.f, 0.f, 0.f}, dxb = dxa, dya = dxa, dyb = dxa, dza = dxa, dzb = dxa;
 #pragma unroll
         for (int j = 1; j <= P; ++j) {
             dxa += a.a[j] * (qa[P + j] - qa[P - j]);
             dxb += a.a[j] * (qb[P + j] - qb[P - j]);
-            dya += a.a[j] * (ld4t(A + px + (long)j * a.s1) - ld4t(A + px - (long)j * a.s1));
-            dyb += a.a[j] * (ld4t(B + px + (long)j * a.s1) - ld4t(B + px - (long)j * a.s1));
+            dya += a.a[j] * (ya[2 * j - 1] - ya[2 * j - 2]);
+            dyb += a.a[j] * (yb[2 * j - 1] - yb[2 * j - 2]);
         }
         {
             float la[V + 8], lb[V + 8];   // z - 4 .. z + 7
 #pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                const tf4 va = c == 1 ? qa[P] : ld4t(A + px + 4 * (c - 1)), vb = c == 1 ? qb[P] : ld4t(B + px + 4 * (c - 1));
-#pragma unroll
-                for (int i = 0; i < V; ++i) la[4 * c + i] = va[i], lb[4 * c + i] = vb[i];
+            for (int i = 0; i < V; ++i) {
+                la[i] = za[0][i], la[4 + i] = qa[P][i], la[8 + i] = za[1][i];
+                lb[i] = zb[0][i], lb[4 + i] = qb[P][i], lb[8 + i] = zb[1][i];
             }
 #pragma unroll
             for (int j = 1; j <= P; ++j)
@@ -592,7 +645,7 @@ __global__ __launch_bounds__(256) void tti3d_step_kernel(Tti3DArgs a)
 {
     constexpr int P = R / 2, TY = 16, TZ = 64, V = 4;
     constexpr int NZ4 = (R + 3) / 4;   // 16-byte pieces of the z line of A on either side
-    int t = blockIdx.x;
+    int t = xcd_contiguous_block();
     const int tile_z = t % a.ntz;
     t /= a.ntz;
     const int tile_y = t % a.nty;
@@ -603,47 +656,88 @@ __global__ __launch_bounds__(256) void tti3d_step_kernel(Tti3DArgs a)
     const int tid = threadIdx.x;
     const int y = tile_y * TY + tid / (TZ / V), z = tile_z * TZ + V * (tid % (TZ / V));
     if (y >= a.n1 || z >= a.n2 || xa >= xb) return;
-    const long col = a.off0 + (long)y * a.s1 + z;   // element offset of (plane 0, y, z) in a level
-    const float *A = a.A + (long)shot * a.a_stride + col;
-    const float *gA = a.gz + (long)shot * a.field + col, *gB = gA + a.gz_stride;
-    const float *wx = a.wx + col, *wy = a.wy + col, *wz = a.wz + col;
-    const long lv = (long)shot * a.lv_stride + col;
+    const unsigned voff = (unsigned)((long)y * a.s1 + z) * 4u;   // bytes from point (x, 0, 0) of a plane
+    const float *A = a.A + (long)shot * a.a_stride + a.off0;
+    const float *gA = a.gz + (long)shot * a.field + a.off0, *gB = gA + a.gz_stride;
+    const float *wx = a.wx + a.off0, *wy = a.wy + a.off0, *wz = a.wz + a.off0;
+    const long lv = (long)shot * a.lv_stride + a.off0;
 
+    // qa[j]: A at plane x - R + j; qxa / qxb[j]: wx Gz of the two fields at plane x - P + j (after the shift)
     tf4 qa[2 * R + 1], qxa[2 * P + 1], qxb[2 * P + 1];
+    {
+        tf4 w[2 * P];
 #pragma unroll
-    for (int j = 0; j < 2 * R; ++j) qa[j + 1] = ld4t(A + (long)(xa - R + j) * a.s0);
+        for (int j = 0; j < 2 * R; ++j) gld<0>(qa[j + 1], voff, A + (long)(xa - R + j) * a.s0);
 #pragma unroll
-    for (int j = 0; j < 2 * P; ++j) {
-        const long o = (long)(xa - P + j) * a.s0;
-        const tf4 w = ld4t(wx + o);
-        qxa[j + 1] = w * ld4t(gA + o), qxb[j + 1] = w * ld4t(gB + o);
+        for (int j = 0; j < 2 * P; ++j) {
+            const long o = (long)(xa - P + j) * a.s0;
+            gld<0>(w[j], voff, wx + o);
+            gld<0>(qxa[j + 1], voff, gA + o);
+            gld<0>(qxb[j + 1], voff, gB + o);
+        }
+        vm_wait<0>();
+#pragma unroll
+        for (int j = 0; j < 2 * R; ++j) arrived(qa[j + 1]);
+#pragma unroll
+        for (int j = 0; j < 2 * P; ++j) {
+            arrived(w[j]), arrived(qxa[j + 1]), arrived(qxb[j + 1]);
+            qxa[j + 1] *= w[j], qxb[j + 1] *= w[j];
+        }
     }
     for (int x = xa; x < xb; ++x) {
         const long px = (long)x * a.s0;
+        const float *Ap = A + px, *gAp = gA + px, *gBp = gB + px, *wyp = wy + px, *wzp = wz + px;
+        // batch 1: the new planes of the queues, rows and line of A
+        tf4 na, nw, nga, ngb, yA[2 * R], zA[2 * NZ4];
+        gld<0>(na, voff, Ap + (long)R * a.s0);
+        gld<0>(nw, voff, wx + px + (long)P * a.s0);
+        gld<0>(nga, voff, gAp + (long)P * a.s0);
+        gld<0>(ngb, voff, gBp + (long)P * a.s0);
+#pragma unroll
+        for (int k = 1; k <= R; ++k) {
+            gld<0>(yA[2 * k - 2], voff, Ap - (long)k * a.s1);
+            gld<0>(yA[2 * k - 1], voff, Ap + (long)k * a.s1);
+        }
+        gld<-16>(zA[0], voff, Ap);
+        gld<16>(zA[1], voff, Ap);
+        if constexpr (NZ4 == 2) {
+            gld<-32>(zA[2], voff, Ap);
+            gld<32>(zA[3], voff, Ap);
+        }
+        // batch 2: rows of wy, Gz(A), Gz(B)
+        tf4 yw[2 * P], yga[2 * P], ygb[2 * P];
+#pragma unroll
+        for (int j = 1; j <= P; ++j) {
+            const long jy = (long)j * a.s1;
+            gld<0>(yw[2 * j - 2], voff, wyp - jy);
+            gld<0>(yw[2 * j - 1], voff, wyp + jy);
+            gld<0>(yga[2 * j - 2], voff, gAp - jy);
+            gld<0>(yga[2 * j - 1], voff, gAp + jy);
+            gld<0>(ygb[2 * j - 2], voff, gBp - jy);
+            gld<0>(ygb[2 * j - 1], voff, gBp + jy);
+        }
+        vm_wait<6 * P>();   // batch 1 has arrived
+        arrived(na), arrived(nw), arrived(nga), arrived(ngb);
+#pragma unroll
+        for (int k = 0; k < 2 * R; ++k) arrived(yA[k]);
+#pragma unroll
+        for (int k = 0; k < 2 * NZ4; ++k) arrived(zA[k]);
 #pragma unroll
         for (int j = 0; j < 2 * R; ++j) qa[j] = qa[j + 1];
-        qa[2 * R] = ld4t(A + px + (long)R * a.s0);
+        qa[2 * R] = na;
 #pragma unroll
         for (int j = 0; j < 2 * P; ++j) qxa[j] = qxa[j + 1], qxb[j] = qxb[j + 1];
-        {
-            const long o = px + (long)P * a.s0;
-            const tf4 w = ld4t(wx + o);
-            qxa[2 * P] = w * ld4t(gA + o), qxb[2 * P] = w * ld4t(gB + o);
-        }
-        // pointwise streams of this plane
-        const tf4 et = ld4t(a.et + col + px), dl = ld4t(a.dl + col + px), mm = ld4t(a.m + col + px), ee = ld4t(a.eta + col + px);
-        const tf4 uc = ld4t(a.ucur + lv + px), uo = ld4t(a.uold + lv + px), vc = ld4t(a.vcur + lv + px), vo = ld4t(a.vold + lv + px);
-
-        // Laplacian of A: z line and y rows from memory, x from the queue
+        qxa[2 * P] = nw * nga, qxb[2 * P] = nw * ngb;
+        // Laplacian of A in the order z, y, x
         const tf4 ac = qa[R];
         tf4 lap = a.c0 * ac;
         {
             float line[V + 8 * NZ4];
 #pragma unroll
-            for (int c = 0; c < 2 * NZ4 + 1; ++c) {
-                const tf4 v = c == NZ4 ? ac : ld4t(A + px + 4 * (c - NZ4));
-#pragma unroll
-                for (int i = 0; i < V; ++i) line[4 * c + i] = v[i];
+            for (int i = 0; i < V; ++i) {
+                line[4 * NZ4 + i] = ac[i];
+                line[4 * NZ4 - 4 + i] = zA[0][i], line[4 * NZ4 + 4 + i] = zA[1][i];
+                if constexpr (NZ4 == 2) line[i] = zA[2][i], line[16 + i] = zA[3][i];
             }
 #pragma unroll
             for (int k = 1; k <= R; ++k)
@@ -651,22 +745,52 @@ __global__ __launch_bounds__(256) void tti3d_step_kernel(Tti3DArgs a)
                 for (int i = 0; i < V; ++i) lap[i] += a.cz[k] * (line[4 * NZ4 + i - k] + line[4 * NZ4 + i + k]);
         }
 #pragma unroll
-        for (int k = 1; k <= R; ++k) lap += a.cy[k] * (ld4t(A + px - (long)k * a.s1) + ld4t(A + px + (long)k * a.s1));
+        for (int k = 1; k <= R; ++k) lap += a.cy[k] * (yA[2 * k - 2] + yA[2 * k - 1]);
 #pragma unroll
         for (int k = 1; k <= R; ++k) lap += a.cx[k] * (qa[R - k] + qa[R + k]);
 
-        // Gzz of both fields: products along z from three pieces of the line, along x from the queues, along y from rows
+        // batch 3: the z line of wz, Gz(A), Gz(B)
+        tf4 zw[3], zga[3], zgb[3];
+        gld<-16>(zw[0], voff, wzp);
+        gld<0>(zw[1], voff, wzp);
+        gld<16>(zw[2], voff, wzp);
+        gld<-16>(zga[0], voff, gAp);
+        gld<0>(zga[1], voff, gAp);
+        gld<16>(zga[2], voff, gAp);
+        gld<-16>(zgb[0], voff, gBp);
+        gld<0>(zgb[1], voff, gBp);
+        gld<16>(zgb[2], voff, gBp);
+        vm_wait<9>();   // batch 2 has arrived
+        tf4 tyA[P], tyB[P];
+#pragma unroll
+        for (int j = 0; j < 2 * P; ++j) arrived(yw[j]), arrived(yga[j]), arrived(ygb[j]);
+#pragma unroll
+        for (int j = 1; j <= P; ++j) {
+            tyA[j - 1] = a.a1[j] * (yw[2 * j - 1] * yga[2 * j - 1] - yw[2 * j - 2] * yga[2 * j - 2]) * a.ih[1];
+            tyB[j - 1] = a.a1[j] * (yw[2 * j - 1] * ygb[2 * j - 1] - yw[2 * j - 2] * ygb[2 * j - 2]) * a.ih[1];
+        }
+        // batch 4: the pointwise streams of this plane
+        tf4 et, dl, mm, ee, uc, uo, vc, vo;
+        gld<0>(et, voff, a.et + a.off0 + px);
+        gld<0>(dl, voff, a.dl + a.off0 + px);
+        gld<0>(mm, voff, a.m + a.off0 + px);
+        gld<0>(ee, voff, a.eta + a.off0 + px);
+        gld<0>(uc, voff, a.ucur + lv + px);
+        gld<0>(uo, voff, a.uold + lv + px);
+        gld<0>(vc, voff, a.vcur + lv + px);
+        gld<0>(vo, voff, a.vold + lv + px);
+        vm_wait<8>();   // batch 3 has arrived
         float za[V + 8], zb[V + 8];
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            const tf4 w = ld4t(wz + px + 4 * (c - 1));
-            const tf4 va = w * ld4t(gA + px + 4 * (c - 1)), vb = w * ld4t(gB + px + 4 * (c - 1));
+            arrived(zw[c]), arrived(zga[c]), arrived(zgb[c]);
+            const tf4 va = zw[c] * zga[c], vb = zw[c] * zgb[c];
 #pragma unroll
             for (int i = 0; i < V; ++i) za[4 * c + i] = va[i], zb[4 * c + i] = vb[i];
         }
         tf4 sA = {0.f, 0.f, 0.f, 0.f}, sB = sA;
 #pragma unroll
-        for (int j = 1; j <= P; ++j) {
+        for (int j = 1; j <= P; ++j) {   // per j: z term, then x, then y, as in tti_gzz
             tf4 tA, tB;
 #pragma unroll
             for (int i = 0; i < V; ++i) {
@@ -675,13 +799,12 @@ __global__ __launch_bounds__(256) void tti3d_step_kernel(Tti3DArgs a)
             }
             tA += a.a1[j] * (qxa[P + j] - qxa[P - j]) * a.ih[0];
             tB += a.a1[j] * (qxb[P + j] - qxb[P - j]) * a.ih[0];
-            const long jy = (long)j * a.s1;
-            const tf4 wp = ld4t(wy + px + jy), wm = ld4t(wy + px - jy);
-            tA += a.a1[j] * (wp * ld4t(gA + px + jy) - wm * ld4t(gA + px - jy)) * a.ih[1];
-            tB += a.a1[j] * (wp * ld4t(gB + px + jy) - wm * ld4t(gB + px - jy)) * a.ih[1];
+            tA += tyA[j - 1], tB += tyB[j - 1];
             sA += tA, sB += tB;
         }
         const tf4 X = lap + sA, Y = -sB;   // Gzz = -s
+        vm_wait<0>();
+        arrived(et), arrived(dl), arrived(mm), arrived(ee), arrived(uc), arrived(uo), arrived(vc), arrived(vo);
         const tf4 H0 = a.fwd ? et * X + dl * Y : X;
         const tf4 Hz = a.fwd ? dl * X + Y : Y;
         tf4 un, vn;
@@ -691,12 +814,13 @@ __global__ __launch_bounds__(256) void tti3d_step_kernel(Tti3DArgs a)
             un[i] = (a.dt2 * H0[i] + 2.0f * mm[i] * uc[i] - mm[i] * uo[i] + ed * uc[i]) / (mm[i] + ed);
             vn[i] = (a.dt2 * Hz[i] + 2.0f * mm[i] * vc[i] - mm[i] * vo[i] + ed * vc[i]) / (mm[i] + ed);
         }
+        float *uo_p = a.uout + lv + px + voff / 4, *vo_p = a.vout + lv + px + voff / 4;
         if (z + V - 1 < a.n2) {
-            *reinterpret_cast<tf4 *>(a.uout + lv + px) = un;
-            *reinterpret_cast<tf4 *>(a.vout + lv + px) = vn;
+            *reinterpret_cast<tf4 *>(uo_p) = un;
+            *reinterpret_cast<tf4 *>(vo_p) = vn;
         } else {
             for (int i = 0; i < V; ++i)
-                if (z + i < a.n2) a.uout[lv + px + i] = un[i], a.vout[lv + px + i] = vn[i];
+                if (z + i < a.n2) uo_p[i] = un[i], vo_p[i] = vn[i];
         }
     }
 }
