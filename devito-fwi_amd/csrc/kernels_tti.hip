@@ -825,11 +825,14 @@ __global__ __launch_bounds__(256) void tti3d_step_kernel(Tti3DArgs a)
     }
 }
 
-// float32 3-D plans that could allocate the tables of the marches (p.tti_gz3, p.tti_w) take them
+// float32 3-D plans that could allocate the tables of the marches (p.tti_gz3, p.tti_w) take them, up to space order
+// 8: beyond it the plane queues and one batch of loads no longer fit in 256 registers, the compiler moves registers
+// whose loads are still in flight, and the results are wrong (seen at order 16) -- those orders keep the kernels
+// with one thread per point.
 static bool tti3d_available(const Plan &p)
 {
     return p.L.ndim == 3 && p.esize == 4 && p.tti_gz3 && p.tti_w && !(p.cfg.flags & MIFWI_FLAG_GENERIC) &&
-           p.L.R % 2 == 0 && p.L.R <= 8;
+           p.L.R % 2 == 0 && p.L.R <= 4;
 }
 
 // wx, wy of the parameter fields of the plan (order in p.tti_par: et, dl, ct, st, cp, sp)
@@ -870,12 +873,10 @@ static int launch_tti3d(const Plan &p, const StepConsts<float> &k, const TtiPara
         tti3d_chunks(p, g.nty * g.ntz * nshots, k.n0 + 2 * q.p, 2 * q.p, 8, g.nchunk, g.xchunk);
         g.nshots = nshots;
         const int nb = g.nty * g.ntz * g.nchunk * nshots;
-        switch (q.p) {
-            case 1: hipLaunchKernelGGL((tti3d_gz_kernel<1>), dim3(nb), dim3(256), 0, p.stream, g); break;
-            case 2: hipLaunchKernelGGL((tti3d_gz_kernel<2>), dim3(nb), dim3(256), 0, p.stream, g); break;
-            case 3: hipLaunchKernelGGL((tti3d_gz_kernel<3>), dim3(nb), dim3(256), 0, p.stream, g); break;
-            default: hipLaunchKernelGGL((tti3d_gz_kernel<4>), dim3(nb), dim3(256), 0, p.stream, g);
-        }
+        if (q.p == 1)
+            hipLaunchKernelGGL((tti3d_gz_kernel<1>), dim3(nb), dim3(256), 0, p.stream, g);
+        else
+            hipLaunchKernelGGL((tti3d_gz_kernel<2>), dim3(nb), dim3(256), 0, p.stream, g);
         MIFWI_HIP(hipGetLastError());
     }
     Tti3DArgs a{};
@@ -894,12 +895,10 @@ static int launch_tti3d(const Plan &p, const StepConsts<float> &k, const TtiPara
     tti3d_chunks(p, a.nty * a.ntz * nshots, k.n0, 2 * p.L.R, 8, a.nchunk, a.xchunk);
     a.nshots = nshots, a.fwd = fwd;
     const int nb = a.nty * a.ntz * a.nchunk * nshots;
-    switch (p.L.R) {
-        case 2: hipLaunchKernelGGL((tti3d_step_kernel<2>), dim3(nb), dim3(256), 0, p.stream, a); break;
-        case 4: hipLaunchKernelGGL((tti3d_step_kernel<4>), dim3(nb), dim3(256), 0, p.stream, a); break;
-        case 6: hipLaunchKernelGGL((tti3d_step_kernel<6>), dim3(nb), dim3(256), 0, p.stream, a); break;
-        default: hipLaunchKernelGGL((tti3d_step_kernel<8>), dim3(nb), dim3(256), 0, p.stream, a);
-    }
+    if (p.L.R == 2)
+        hipLaunchKernelGGL((tti3d_step_kernel<2>), dim3(nb), dim3(256), 0, p.stream, a);
+    else
+        hipLaunchKernelGGL((tti3d_step_kernel<4>), dim3(nb), dim3(256), 0, p.stream, a);
     MIFWI_HIP(hipGetLastError());
     launches += 2;
     return MIFWI_OK;

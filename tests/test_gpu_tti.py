@@ -86,6 +86,34 @@ def test_tti_tiled_kernel_matches_untiled_and_oracle(mifwi, shape, so):
         assert rel_l2(out["tiled"][1][s], prob.adjoint(src[s], rec[s], ref, dt=dt)) <= 1e-4
 
 
+@pytest.mark.parametrize("shape,so", [((40, 21, 70), 16), ((30, 19, 23), 12), ((25, 37, 131), 8), ((20, 18, 30), 4)])
+def test_tti_3d_marching_kernels_match_untiled_and_oracle(mifwi, shape, so):
+    """float32 3-D plans up to space order 8 step with the two marching kernels (ragged tiles in y and z, several
+    chunks of planes, two shots); higher orders and FLAG_GENERIC keep the kernels with one thread per point."""
+    prob, vp, src0, rec0, rng = tti_case(shape, so=so, dtype=np.float32)
+    dt, nt, nshots = float(prob.critical_dt), 40, 2
+    dom = np.array([(n - 1) * 10. for n in shape])
+    src = ((rng.random((nshots, 1, 3)) * 0.5 + 0.25) * dom).astype(np.float32)
+    rec = ((rng.random((nshots, 7, 3)) * 0.9 + 0.05) * dom).astype(np.float32)
+    w = (orc.ricker(0.03, dt * np.arange(nt))[None, :, None] * (1 + np.arange(nshots))[:, None, None]).astype(np.float32)
+    out = {}
+    for name, flags in (("march", 0), ("untiled", mifwi.FLAG_GENERIC)):
+        plan = mifwi.Plan(prob.shape_pad, prob.spacing, prob.origin_pad, so, nt, dt, 1, 7, max_shots=nshots,
+                          dtype=np.float32, flags=flags)
+        plan.set_model(prob.vp, prob.damp)
+        plan.tti_set_model(prob.epsilon, prob.delta, prob.theta, prob.phi)
+        plan.set_geometry(src, rec, rec_per_shot=True)
+        d = plan.tti_forward(w, wavelet_per_shot=True)
+        a = plan.tti_adjoint(d)
+        out[name] = (d, a, plan.read_wavefield(3, shot=1), plan.read_wavefield(6, shot=0))
+        plan.close()
+    for x, y in zip(out["march"], out["untiled"]):
+        assert np.abs(y).max() > 0 and rel_l2(x, y) <= 5e-5   # float32 rounding (different contraction)
+    ref = prob.forward(src[1], w[1], rec[1], dt=dt)
+    assert rel_l2(out["march"][0][1], ref) <= 2e-5
+    assert rel_l2(out["march"][1][1], prob.adjoint(src[1], rec[1], ref, dt=dt)) <= 1e-4
+
+
 @pytest.mark.parametrize("dtype,tol", [(np.float32, 5e-5), (np.float64, 1e-10)])
 @pytest.mark.parametrize("shape,so", [((41, 37), 8), ((60, 75), 16), ((17, 15, 19), 4)])
 def test_tti_jacobian_pair_parity(mifwi, shape, so, dtype, tol):
