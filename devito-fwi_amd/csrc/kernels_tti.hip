@@ -684,15 +684,15 @@ __global__ __launch_bounds__(256) void tti3d_step_kernel(Tti3DArgs a)
             qxa[j + 1] *= w[j], qxb[j + 1] *= w[j];
         }
     }
-    for (int x = xa; x < xb; ++x) {
-        const long px = (long)x * a.s0;
-        const float *Ap = A + px, *gAp = gA + px, *gBp = gB + px, *wyp = wy + px, *wzp = wz + px;
-        // batch 1: the new planes of the queues, rows and line of A
-        tf4 na, nw, nga, ngb, yA[2 * R], zA[2 * NZ4];
+    // batch 1 of a plane: the new planes of the queues, rows and line of A.  (Issued a plane ahead it would overlap
+    // the update, but its registers then live across the loop edge and the compiler copies them there, in flight.)
+    tf4 na, nw, nga, ngb, yA[2 * R], zA[2 * NZ4];
+    auto issue_b1 = [&](long px) {
+        const float *Ap = A + px;
         gld<0>(na, voff, Ap + (long)R * a.s0);
         gld<0>(nw, voff, wx + px + (long)P * a.s0);
-        gld<0>(nga, voff, gAp + (long)P * a.s0);
-        gld<0>(ngb, voff, gBp + (long)P * a.s0);
+        gld<0>(nga, voff, gA + px + (long)P * a.s0);
+        gld<0>(ngb, voff, gB + px + (long)P * a.s0);
 #pragma unroll
         for (int k = 1; k <= R; ++k) {
             gld<0>(yA[2 * k - 2], voff, Ap - (long)k * a.s1);
@@ -704,6 +704,18 @@ __global__ __launch_bounds__(256) void tti3d_step_kernel(Tti3DArgs a)
             gld<-32>(zA[2], voff, Ap);
             gld<32>(zA[3], voff, Ap);
         }
+    };
+    auto b1_arrived = [&]() {
+        arrived(na), arrived(nw), arrived(nga), arrived(ngb);
+#pragma unroll
+        for (int k = 0; k < 2 * R; ++k) arrived(yA[k]);
+#pragma unroll
+        for (int k = 0; k < 2 * NZ4; ++k) arrived(zA[k]);
+    };
+    for (int x = xa; x < xb; ++x) {
+        const long px = (long)x * a.s0;
+        const float *gAp = gA + px, *gBp = gB + px, *wyp = wy + px, *wzp = wz + px;
+        issue_b1(px);
         // batch 2: rows of wy, Gz(A), Gz(B)
         tf4 yw[2 * P], yga[2 * P], ygb[2 * P];
 #pragma unroll
@@ -717,11 +729,7 @@ __global__ __launch_bounds__(256) void tti3d_step_kernel(Tti3DArgs a)
             gld<0>(ygb[2 * j - 1], voff, gBp + jy);
         }
         vm_wait<6 * P>();   // batch 1 has arrived
-        arrived(na), arrived(nw), arrived(nga), arrived(ngb);
-#pragma unroll
-        for (int k = 0; k < 2 * R; ++k) arrived(yA[k]);
-#pragma unroll
-        for (int k = 0; k < 2 * NZ4; ++k) arrived(zA[k]);
+        b1_arrived();
 #pragma unroll
         for (int j = 0; j < 2 * R; ++j) qa[j] = qa[j + 1];
         qa[2 * R] = na;
@@ -749,7 +757,7 @@ __global__ __launch_bounds__(256) void tti3d_step_kernel(Tti3DArgs a)
 #pragma unroll
         for (int k = 1; k <= R; ++k) lap += a.cx[k] * (qa[R - k] + qa[R + k]);
 
-        // batch 3: the z line of wz, Gz(A), Gz(B)
+        // batch 3: the z line of wz, Gz(A), Gz(B); batch 4: the pointwise streams of this plane
         tf4 zw[3], zga[3], zgb[3];
         gld<-16>(zw[0], voff, wzp);
         gld<0>(zw[1], voff, wzp);
@@ -760,16 +768,6 @@ __global__ __launch_bounds__(256) void tti3d_step_kernel(Tti3DArgs a)
         gld<-16>(zgb[0], voff, gBp);
         gld<0>(zgb[1], voff, gBp);
         gld<16>(zgb[2], voff, gBp);
-        vm_wait<9>();   // batch 2 has arrived
-        tf4 tyA[P], tyB[P];
-#pragma unroll
-        for (int j = 0; j < 2 * P; ++j) arrived(yw[j]), arrived(yga[j]), arrived(ygb[j]);
-#pragma unroll
-        for (int j = 1; j <= P; ++j) {
-            tyA[j - 1] = a.a1[j] * (yw[2 * j - 1] * yga[2 * j - 1] - yw[2 * j - 2] * yga[2 * j - 2]) * a.ih[1];
-            tyB[j - 1] = a.a1[j] * (yw[2 * j - 1] * ygb[2 * j - 1] - yw[2 * j - 2] * ygb[2 * j - 2]) * a.ih[1];
-        }
-        // batch 4: the pointwise streams of this plane
         tf4 et, dl, mm, ee, uc, uo, vc, vo;
         gld<0>(et, voff, a.et + a.off0 + px);
         gld<0>(dl, voff, a.dl + a.off0 + px);
@@ -779,6 +777,15 @@ __global__ __launch_bounds__(256) void tti3d_step_kernel(Tti3DArgs a)
         gld<0>(uo, voff, a.uold + lv + px);
         gld<0>(vc, voff, a.vcur + lv + px);
         gld<0>(vo, voff, a.vold + lv + px);
+        vm_wait<17>();   // batch 2 has arrived
+        tf4 tyA[P], tyB[P];
+#pragma unroll
+        for (int j = 0; j < 2 * P; ++j) arrived(yw[j]), arrived(yga[j]), arrived(ygb[j]);
+#pragma unroll
+        for (int j = 1; j <= P; ++j) {
+            tyA[j - 1] = a.a1[j] * (yw[2 * j - 1] * yga[2 * j - 1] - yw[2 * j - 2] * yga[2 * j - 2]) * a.ih[1];
+            tyB[j - 1] = a.a1[j] * (yw[2 * j - 1] * ygb[2 * j - 1] - yw[2 * j - 2] * ygb[2 * j - 2]) * a.ih[1];
+        }
         vm_wait<8>();   // batch 3 has arrived
         float za[V + 8], zb[V + 8];
 #pragma unroll
@@ -803,7 +810,7 @@ __global__ __launch_bounds__(256) void tti3d_step_kernel(Tti3DArgs a)
             sA += tA, sB += tB;
         }
         const tf4 X = lap + sA, Y = -sB;   // Gzz = -s
-        vm_wait<0>();
+        vm_wait<0>();   // batch 4 has arrived
         arrived(et), arrived(dl), arrived(mm), arrived(ee), arrived(uc), arrived(uo), arrived(vc), arrived(vo);
         const tf4 H0 = a.fwd ? et * X + dl * Y : X;
         const tf4 Hz = a.fwd ? dl * X + Y : Y;
