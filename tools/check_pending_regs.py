@@ -42,10 +42,11 @@ def check(lines, name):
     return bad
 
 
-def main():
-    s = open(sys.argv[1]).read()
-    total = 0
-    for frag in sys.argv[2:]:
+def check_file(path, frags):
+    """Number of violations over every function of `path` whose name contains one of `frags` (and how many matched)."""
+    s = open(path).read()
+    total, nfun = 0, 0
+    for frag in frags:
         for m in re.finditer(r"^(\S*%s\S*):[^\n]*\n" % re.escape(frag), s, re.M):
             body = s[m.end():s.index("s_endpgm", m.end())].split("\n")
             labels = {mm.group(1): n for n, l in enumerate(body) for mm in [re.match(r"^(\.LBB\d+_\d+):", l)] if mm}
@@ -55,7 +56,9 @@ def main():
                 a, b = max(loops, key=lambda t: t[1] - t[0])
                 body = body[:b + 1] + body[a:b + 1] + body[b + 1:]
             total += check(body, m.group(1))
-    sys.exit(1 if total else 0)
+            nfun += 1
+    return total, nfun
 
 
-main()
+if __name__ == "__main__":
+    sys.exit(1 if check_file(sys.argv[1], sys.argv[2:])[0] else 0)
