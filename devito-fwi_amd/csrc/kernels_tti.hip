@@ -486,6 +486,9 @@ static int launch_tti_step_r(const Plan &p, const StepConsts<T> &k, const TtiPar
 // this part, so the first march stores Gz of the two fields only and the second forms the products with the
 // direction cosines (wx = st cp and wy = st sp, tabulated once per model; wz = ct) at the neighbouring points itself.
 // ------------------------------------------------------------------------------------------------
+#ifndef TTI3D_TY
+#define TTI3D_TY 16   // rows of a tile of the marching kernels (16 threads of four points per row)
+#endif
 typedef float tf4 __attribute__((ext_vector_type(4)));
 
 // The loads of the two marches are issued by hand, in batches, each followed by one wait: left to the compiler's
@@ -536,9 +539,9 @@ struct Tti3DGzArgs {
 };
 
 template <int P>
-__global__ __launch_bounds__(256) void tti3d_gz_kernel(Tti3DGzArgs a)
+__global__ __launch_bounds__(16 * TTI3D_TY) void tti3d_gz_kernel(Tti3DGzArgs a)
 {
-    constexpr int TY = 16, TZ = 64, V = 4;
+    constexpr int TY = TTI3D_TY, TZ = 64, V = 4;
     int t = xcd_contiguous_block();
     const int tile_z = t % a.ntz;
     t /= a.ntz;
@@ -641,9 +644,9 @@ struct Tti3DArgs {
 };
 
 template <int R>
-__global__ __launch_bounds__(256) void tti3d_step_kernel(Tti3DArgs a)
+__global__ __launch_bounds__(16 * TTI3D_TY) void tti3d_step_kernel(Tti3DArgs a)
 {
-    constexpr int P = R / 2, TY = 16, TZ = 64, V = 4;
+    constexpr int P = R / 2, TY = TTI3D_TY, TZ = 64, V = 4;
     constexpr int NZ4 = (R + 3) / 4;   // 16-byte pieces of the z line of A on either side
     int t = xcd_contiguous_block();
     const int tile_z = t % a.ntz;
@@ -876,14 +879,14 @@ static int launch_tti3d(const Plan &p, const StepConsts<float> &k, const TtiPara
         g.ih[0] = q.ih[0], g.ih[1] = q.ih[1], g.ih[2] = q.ih[2];
         g.n0 = k.n0, g.n1 = k.n1, g.n2 = k.n2, g.e = q.p, g.zl = p.L.zl;
         g.s0 = k.s0, g.s1 = k.s1, g.off0 = k.off0, g.field = k.field;
-        g.nty = (k.n1 + 2 * q.p + 15) / 16, g.ntz = (p.L.zl + k.n2 + q.p + 63) / 64;
+        g.nty = (k.n1 + 2 * q.p + TTI3D_TY - 1) / TTI3D_TY, g.ntz = (p.L.zl + k.n2 + q.p + 63) / 64;
         tti3d_chunks(p, g.nty * g.ntz * nshots, k.n0 + 2 * q.p, 2 * q.p, 8, g.nchunk, g.xchunk);
         g.nshots = nshots;
         const int nb = g.nty * g.ntz * g.nchunk * nshots;
         if (q.p == 1)
-            hipLaunchKernelGGL((tti3d_gz_kernel<1>), dim3(nb), dim3(256), 0, p.stream, g);
+            hipLaunchKernelGGL((tti3d_gz_kernel<1>), dim3(nb), dim3(16 * TTI3D_TY), 0, p.stream, g);
         else
-            hipLaunchKernelGGL((tti3d_gz_kernel<2>), dim3(nb), dim3(256), 0, p.stream, g);
+            hipLaunchKernelGGL((tti3d_gz_kernel<2>), dim3(nb), dim3(16 * TTI3D_TY), 0, p.stream, g);
         MIFWI_HIP(hipGetLastError());
     }
     Tti3DArgs a{};
@@ -898,14 +901,14 @@ static int launch_tti3d(const Plan &p, const StepConsts<float> &k, const TtiPara
     a.ih[0] = q.ih[0], a.ih[1] = q.ih[1], a.ih[2] = q.ih[2];
     a.dt = k.dt, a.dt2 = k.dt2;
     a.n0 = k.n0, a.n1 = k.n1, a.n2 = k.n2, a.s0 = k.s0, a.s1 = k.s1, a.off0 = k.off0, a.field = k.field;
-    a.nty = (k.n1 + 15) / 16, a.ntz = (k.n2 + 63) / 64;
+    a.nty = (k.n1 + TTI3D_TY - 1) / TTI3D_TY, a.ntz = (k.n2 + 63) / 64;
     tti3d_chunks(p, a.nty * a.ntz * nshots, k.n0, 2 * p.L.R, 8, a.nchunk, a.xchunk);
     a.nshots = nshots, a.fwd = fwd;
     const int nb = a.nty * a.ntz * a.nchunk * nshots;
     if (p.L.R == 2)
-        hipLaunchKernelGGL((tti3d_step_kernel<2>), dim3(nb), dim3(256), 0, p.stream, a);
+        hipLaunchKernelGGL((tti3d_step_kernel<2>), dim3(nb), dim3(16 * TTI3D_TY), 0, p.stream, a);
     else
-        hipLaunchKernelGGL((tti3d_step_kernel<4>), dim3(nb), dim3(256), 0, p.stream, a);
+        hipLaunchKernelGGL((tti3d_step_kernel<4>), dim3(nb), dim3(16 * TTI3D_TY), 0, p.stream, a);
     MIFWI_HIP(hipGetLastError());
     launches += 2;
     return MIFWI_OK;
