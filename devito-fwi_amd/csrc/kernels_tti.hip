@@ -248,20 +248,22 @@ __global__ __launch_bounds__(256) void tti2d_kernel(Tti2DArgs a)
     const int tz = tid & (TZ - 1);
     const int ty = TZ == 32 ? (tid >> 6) + 4 * ((tid >> 5) & 1) : (tid >> 6);
     const int z = z0 + tz;
+    // Every load of the block is issued before the first wait: a point outside the grid reads grid point (0, 0)
+    // instead of branching around its load (behind a branch each load waited for the one before it: NSTG + 2 round
+    // trips to memory per block instead of one), and its value is replaced afterwards.
     float pm[NPT], pe[NPT], pet[NPT], pdl[NPT], puo[NPT], pvo[NPT], puc[NPT], pvc[NPT];
 #pragma unroll
     for (int k = 0; k < NPT; ++k) {
         const int x = x0 + ty + RP * k;
-        pm[k] = 1.f, pe[k] = 0.f, pet[k] = 1.f, pdl[k] = 1.f, puo[k] = 0.f, pvo[k] = 0.f, puc[k] = 0.f, pvc[k] = 0.f;
-        if (x < a.n1 && z < a.n2) {
-            const long i = a.off0 + (long)x * a.s1 + z;
-            pm[k] = a.m[i], pe[k] = a.eta[i];
-            puo[k] = a.uold[sbase + i], pvo[k] = a.vold[sbase + i];
-            if (FWD) {
-                pet[k] = a.et[i], pdl[k] = a.dl[i];
-            } else {
-                puc[k] = ucur[i], pvc[k] = vcur[i];
-            }
+        const bool ok = x < a.n1 && z < a.n2;
+        const long i = ok ? a.off0 + (long)x * a.s1 + z : a.off0;
+        pm[k] = a.m[i], pe[k] = a.eta[i];
+        puo[k] = a.uold[sbase + i], pvo[k] = a.vold[sbase + i];
+        pet[k] = 1.f, pdl[k] = 1.f, puc[k] = 0.f, pvc[k] = 0.f;
+        if (FWD) {
+            pet[k] = a.et[i], pdl[k] = a.dl[i];
+        } else {
+            puc[k] = ucur[i], pvc[k] = vcur[i];
         }
     }
     // angle fields at this thread's points of the extended tile
@@ -271,34 +273,40 @@ __global__ __launch_bounds__(256) void tti2d_kernel(Tti2DArgs a)
         const int e = tid + NT * n;
         const int r = e / LE, c = e - r * LE;
         const int gx = x0 - P + r, gz = z0 - P + c;
-        ect[n] = 1.f, est[n] = 0.f;
-        if (e < HE * LE && gx < a.n1 + P && gz < a.n2 + P) {
-            const long i = a.off0 + (long)gx * a.s1 + gz;
-            ect[n] = a.ct[i], est[n] = a.st[i];
-        }
+        const bool ok = e < HE * LE && gx < a.n1 + P && gz < a.n2 + P;
+        const long i = ok ? a.off0 + (long)gx * a.s1 + gz : a.off0;
+        const float cv = a.ct[i], sv = a.st[i];
+        ect[n] = ok ? cv : 1.f, est[n] = ok ? sv : 0.f;
     }
 
     // ---- stage the two stencilled fields (halo R) --------------------------------------------------
+    {
+        float su[NSTG], sv[NSTG], set[NSTG], sdl[NSTG];
 #pragma unroll
-    for (int n = 0; n < NSTG; ++n) {
-        const int e = tid + NT * n;
-        const int r = e / LA, c = e - r * LA;
-        const int gx = x0 - R + r, gz = z0 - R + c;
-        if (e < HA * LA) {
-            float fa = 0.f, fb = 0.f;
-            if (gx < a.n1 + R && gz < a.n2 + R) {
-                const long i = a.off0 + (long)gx * a.s1 + gz;
-                const float uu = ucur[i], vv = vcur[i];
-                if (FWD) {
-                    fa = uu, fb = vv;
-                } else {
-                    const float et = a.et[i], dl = a.dl[i];
-                    fa = et * uu + dl * vv;
-                    fb = dl * uu + vv;
+        for (int n = 0; n < NSTG; ++n) {
+            const int e = tid + NT * n;
+            const int r = e / LA, c = e - r * LA;
+            const int gx = x0 - R + r, gz = z0 - R + c;
+            const bool ok = e < HA * LA && gx < a.n1 + R && gz < a.n2 + R;
+            const long i = ok ? a.off0 + (long)gx * a.s1 + gz : a.off0;
+            su[n] = ucur[i], sv[n] = vcur[i];
+            if (!FWD) set[n] = a.et[i], sdl[n] = a.dl[i];
+        }
+#pragma unroll
+        for (int n = 0; n < NSTG; ++n) {
+            const int e = tid + NT * n;
+            const int r = e / LA, c = e - r * LA;
+            const int gx = x0 - R + r, gz = z0 - R + c;
+            if (e < HA * LA) {
+                const bool ok = gx < a.n1 + R && gz < a.n2 + R;
+                float fa = su[n], fb = sv[n];
+                if (!FWD) {
+                    fa = set[n] * su[n] + sdl[n] * sv[n];
+                    fb = sdl[n] * su[n] + sv[n];
                 }
+                sA[r * WA + c] = ok ? fa : 0.f;
+                sB[r * WA + c] = ok ? fb : 0.f;
             }
-            sA[r * WA + c] = fa;
-            sB[r * WA + c] = fb;
         }
     }
     if (ninj > 0) {
