@@ -843,14 +843,205 @@ __global__ __launch_bounds__(16 * TTI3D_TY) void tti3d_step_kernel(Tti3DArgs a)
     }
 }
 
-// float32 3-D plans that could allocate the tables of the marches (p.tti_gz3, p.tti_w) take them, up to space order
-// 8: beyond it the plane queues and one batch of loads no longer fit in 256 registers, the compiler moves registers
-// whose loads are still in flight, and the results are wrong (seen at order 16) -- those orders keep the kernels
-// with one thread per point.
+// The same step at radius 6 and 8, where the plane queues alone take 108 and 140 registers: the loads of a plane go
+// out in five smaller groups (at most 17 in flight), each consumed before the next is issued, and the y terms of Gzz
+// are folded in two rows at a time.  Same arithmetic, in the same order.
+template <int R>
+__global__ __launch_bounds__(16 * TTI3D_TY) void tti3d_step_wide_kernel(Tti3DArgs a)
+{
+    constexpr int P = R / 2, TY = TTI3D_TY, TZ = 64, V = 4, NZ4 = 2, H = R / 2;
+    static_assert(R == 6 || R == 8, "radius");
+    int t = xcd_contiguous_block();
+    const int tile_z = t % a.ntz;
+    t /= a.ntz;
+    const int tile_y = t % a.nty;
+    t /= a.nty;
+    const int chunk = t % a.nchunk;
+    const int shot = t / a.nchunk;
+    const int xa = chunk * a.xchunk, xb = min(a.n0, xa + a.xchunk);
+    const int tid = threadIdx.x;
+    const int y = tile_y * TY + tid / (TZ / V), z = tile_z * TZ + V * (tid % (TZ / V));
+    if (y >= a.n1 || z >= a.n2 || xa >= xb) return;
+    const unsigned voff = (unsigned)((long)y * a.s1 + z) * 4u;
+    const float *A = a.A + (long)shot * a.a_stride + a.off0;
+    const float *gA = a.gz + (long)shot * a.field + a.off0, *gB = gA + a.gz_stride;
+    const float *wx = a.wx + a.off0, *wy = a.wy + a.off0, *wz = a.wz + a.off0;
+    const long lv = (long)shot * a.lv_stride + a.off0;
+
+    tf4 qa[2 * R + 1], qxa[2 * P + 1], qxb[2 * P + 1];
+#pragma unroll
+    for (int j = 0; j < 2 * R; ++j) gld<0>(qa[j + 1], voff, A + (long)(xa - R + j) * a.s0);
+    vm_wait<0>();
+#pragma unroll
+    for (int j = 0; j < 2 * R; ++j) arrived(qa[j + 1]);
+#pragma unroll
+    for (int j = 0; j < 2 * P; ++j) {
+        const long o = (long)(xa - P + j) * a.s0;
+        tf4 w;
+        gld<0>(w, voff, wx + o);
+        gld<0>(qxa[j + 1], voff, gA + o);
+        gld<0>(qxb[j + 1], voff, gB + o);
+        vm_wait<0>();
+        arrived(w), arrived(qxa[j + 1]), arrived(qxb[j + 1]);
+        qxa[j + 1] *= w, qxb[j + 1] *= w;
+    }
+    for (int x = xa; x < xb; ++x) {
+        const long px = (long)x * a.s0;
+        const float *Ap = A + px, *gAp = gA + px, *gBp = gB + px, *wyp = wy + px, *wzp = wz + px;
+        tf4 lap;
+        {
+            // group 1: the new planes of the queues, the z line of A and its nearer rows
+            tf4 na, nw, nga, ngb, zA[4], yA[2 * H];
+            gld<0>(na, voff, Ap + (long)R * a.s0);
+            gld<0>(nw, voff, wx + px + (long)P * a.s0);
+            gld<0>(nga, voff, gAp + (long)P * a.s0);
+            gld<0>(ngb, voff, gBp + (long)P * a.s0);
+            gld<-16>(zA[0], voff, Ap);
+            gld<16>(zA[1], voff, Ap);
+            gld<-32>(zA[2], voff, Ap);
+            gld<32>(zA[3], voff, Ap);
+#pragma unroll
+            for (int k = 1; k <= H; ++k) {
+                gld<0>(yA[2 * k - 2], voff, Ap - (long)k * a.s1);
+                gld<0>(yA[2 * k - 1], voff, Ap + (long)k * a.s1);
+            }
+            vm_wait<0>();
+            arrived(na), arrived(nw), arrived(nga), arrived(ngb);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) arrived(zA[k]);
+#pragma unroll
+            for (int k = 0; k < 2 * H; ++k) arrived(yA[k]);
+#pragma unroll
+            for (int j = 0; j < 2 * R; ++j) qa[j] = qa[j + 1];
+            qa[2 * R] = na;
+#pragma unroll
+            for (int j = 0; j < 2 * P; ++j) qxa[j] = qxa[j + 1], qxb[j] = qxb[j + 1];
+            qxa[2 * P] = nw * nga, qxb[2 * P] = nw * ngb;
+            const tf4 ac = qa[R];
+            lap = a.c0 * ac;
+            float line[V + 8 * NZ4];
+#pragma unroll
+            for (int i = 0; i < V; ++i)
+                line[i] = zA[2][i], line[4 + i] = zA[0][i], line[8 + i] = ac[i], line[12 + i] = zA[1][i], line[16 + i] = zA[3][i];
+#pragma unroll
+            for (int k = 1; k <= R; ++k)
+#pragma unroll
+                for (int i = 0; i < V; ++i) lap[i] += a.cz[k] * (line[8 + i - k] + line[8 + i + k]);
+#pragma unroll
+            for (int k = 1; k <= H; ++k) lap += a.cy[k] * (yA[2 * k - 2] + yA[2 * k - 1]);
+        }
+        float za[V + 8], zb[V + 8];
+        {
+            // group 2: the farther rows of A and the z line of wz, Gz(A), Gz(B)
+            tf4 yA[2 * (R - H)], zw[3], zga[3], zgb[3];
+#pragma unroll
+            for (int k = H + 1; k <= R; ++k) {
+                gld<0>(yA[2 * (k - H) - 2], voff, Ap - (long)k * a.s1);
+                gld<0>(yA[2 * (k - H) - 1], voff, Ap + (long)k * a.s1);
+            }
+            gld<-16>(zw[0], voff, wzp);
+            gld<0>(zw[1], voff, wzp);
+            gld<16>(zw[2], voff, wzp);
+            gld<-16>(zga[0], voff, gAp);
+            gld<0>(zga[1], voff, gAp);
+            gld<16>(zga[2], voff, gAp);
+            gld<-16>(zgb[0], voff, gBp);
+            gld<0>(zgb[1], voff, gBp);
+            gld<16>(zgb[2], voff, gBp);
+            vm_wait<9>();
+#pragma unroll
+            for (int k = 0; k < 2 * (R - H); ++k) arrived(yA[k]);
+#pragma unroll
+            for (int k = H + 1; k <= R; ++k) lap += a.cy[k] * (yA[2 * (k - H) - 2] + yA[2 * (k - H) - 1]);
+#pragma unroll
+            for (int k = 1; k <= R; ++k) lap += a.cx[k] * (qa[R - k] + qa[R + k]);
+            vm_wait<0>();
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                arrived(zw[c]), arrived(zga[c]), arrived(zgb[c]);
+                const tf4 va = zw[c] * zga[c], vb = zw[c] * zgb[c];
+#pragma unroll
+                for (int i = 0; i < V; ++i) za[4 * c + i] = va[i], zb[4 * c + i] = vb[i];
+            }
+        }
+        // groups 3: rows of wy, Gz(A), Gz(B), two distances at a time; per j: z term, then x, then y, as in tti_gzz
+        tf4 sA = {0.f, 0.f, 0.f, 0.f}, sB = sA;
+#pragma unroll
+        for (int j0 = 1; j0 <= P; j0 += 2) {
+            constexpr int NJ = 2;
+            tf4 yw[2 * NJ], yga[2 * NJ], ygb[2 * NJ];
+#pragma unroll
+            for (int jj = 0; jj < NJ; ++jj) {
+                const int j = j0 + jj;
+                if (j > P) continue;
+                const long jy = (long)j * a.s1;
+                gld<0>(yw[2 * jj], voff, wyp - jy);
+                gld<0>(yw[2 * jj + 1], voff, wyp + jy);
+                gld<0>(yga[2 * jj], voff, gAp - jy);
+                gld<0>(yga[2 * jj + 1], voff, gAp + jy);
+                gld<0>(ygb[2 * jj], voff, gBp - jy);
+                gld<0>(ygb[2 * jj + 1], voff, gBp + jy);
+            }
+            vm_wait<0>();
+#pragma unroll
+            for (int jj = 0; jj < NJ; ++jj) {
+                const int j = j0 + jj;
+                if (j > P) continue;
+                arrived(yw[2 * jj]), arrived(yw[2 * jj + 1]), arrived(yga[2 * jj]), arrived(yga[2 * jj + 1]);
+                arrived(ygb[2 * jj]), arrived(ygb[2 * jj + 1]);
+                tf4 tA, tB;
+#pragma unroll
+                for (int i = 0; i < V; ++i) {
+                    tA[i] = a.a1[j] * (za[4 + i + j] - za[4 + i - j]) * a.ih[2];
+                    tB[i] = a.a1[j] * (zb[4 + i + j] - zb[4 + i - j]) * a.ih[2];
+                }
+                tA += a.a1[j] * (qxa[P + j] - qxa[P - j]) * a.ih[0];
+                tB += a.a1[j] * (qxb[P + j] - qxb[P - j]) * a.ih[0];
+                tA += a.a1[j] * (yw[2 * jj + 1] * yga[2 * jj + 1] - yw[2 * jj] * yga[2 * jj]) * a.ih[1];
+                tB += a.a1[j] * (yw[2 * jj + 1] * ygb[2 * jj + 1] - yw[2 * jj] * ygb[2 * jj]) * a.ih[1];
+                sA += tA, sB += tB;
+            }
+        }
+        const tf4 X = lap + sA, Y = -sB;   // Gzz = -s
+        // group 4: the pointwise streams of this plane
+        tf4 et, dl, mm, ee, uc, uo, vc, vo;
+        gld<0>(et, voff, a.et + a.off0 + px);
+        gld<0>(dl, voff, a.dl + a.off0 + px);
+        gld<0>(mm, voff, a.m + a.off0 + px);
+        gld<0>(ee, voff, a.eta + a.off0 + px);
+        gld<0>(uc, voff, a.ucur + lv + px);
+        gld<0>(uo, voff, a.uold + lv + px);
+        gld<0>(vc, voff, a.vcur + lv + px);
+        gld<0>(vo, voff, a.vold + lv + px);
+        vm_wait<0>();
+        arrived(et), arrived(dl), arrived(mm), arrived(ee), arrived(uc), arrived(uo), arrived(vc), arrived(vo);
+        const tf4 H0 = a.fwd ? et * X + dl * Y : X;
+        const tf4 Hz = a.fwd ? dl * X + Y : Y;
+        tf4 un, vn;
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+            const float ed = ee[i] * a.dt;
+            un[i] = (a.dt2 * H0[i] + 2.0f * mm[i] * uc[i] - mm[i] * uo[i] + ed * uc[i]) / (mm[i] + ed);
+            vn[i] = (a.dt2 * Hz[i] + 2.0f * mm[i] * vc[i] - mm[i] * vo[i] + ed * vc[i]) / (mm[i] + ed);
+        }
+        float *uo_p = a.uout + lv + px + voff / 4, *vo_p = a.vout + lv + px + voff / 4;
+        if (z + V - 1 < a.n2) {
+            *reinterpret_cast<tf4 *>(uo_p) = un;
+            *reinterpret_cast<tf4 *>(vo_p) = vn;
+        } else {
+            for (int i = 0; i < V; ++i)
+                if (z + i < a.n2) uo_p[i] = un[i], vo_p[i] = vn[i];
+        }
+    }
+}
+
+// float32 3-D plans that could allocate the tables of the marches (p.tti_gz3, p.tti_w) take them.  (At radius 6
+// and 8 the batches of tti3d_step_kernel and the plane queues do not fit in 256 registers together; the compiler then
+// moves registers whose loads are still in flight and the results are wrong -- hence tti3d_step_wide_kernel.)
 static bool tti3d_available(const Plan &p)
 {
     return p.L.ndim == 3 && p.esize == 4 && p.tti_gz3 && p.tti_w && !(p.cfg.flags & MIFWI_FLAG_GENERIC) &&
-           p.L.R % 2 == 0 && p.L.R <= 4;
+           p.L.R % 2 == 0 && p.L.R <= 8;
 }
 
 // wx, wy of the parameter fields of the plan (order in p.tti_par: et, dl, ct, st, cp, sp)
@@ -891,10 +1082,12 @@ static int launch_tti3d(const Plan &p, const StepConsts<float> &k, const TtiPara
         tti3d_chunks(p, g.nty * g.ntz * nshots, k.n0 + 2 * q.p, 2 * q.p, 8, g.nchunk, g.xchunk);
         g.nshots = nshots;
         const int nb = g.nty * g.ntz * g.nchunk * nshots;
-        if (q.p == 1)
-            hipLaunchKernelGGL((tti3d_gz_kernel<1>), dim3(nb), dim3(16 * TTI3D_TY), 0, p.stream, g);
-        else
-            hipLaunchKernelGGL((tti3d_gz_kernel<2>), dim3(nb), dim3(16 * TTI3D_TY), 0, p.stream, g);
+        switch (q.p) {
+            case 1: hipLaunchKernelGGL((tti3d_gz_kernel<1>), dim3(nb), dim3(16 * TTI3D_TY), 0, p.stream, g); break;
+            case 2: hipLaunchKernelGGL((tti3d_gz_kernel<2>), dim3(nb), dim3(16 * TTI3D_TY), 0, p.stream, g); break;
+            case 3: hipLaunchKernelGGL((tti3d_gz_kernel<3>), dim3(nb), dim3(16 * TTI3D_TY), 0, p.stream, g); break;
+            default: hipLaunchKernelGGL((tti3d_gz_kernel<4>), dim3(nb), dim3(16 * TTI3D_TY), 0, p.stream, g);
+        }
         MIFWI_HIP(hipGetLastError());
     }
     Tti3DArgs a{};
@@ -913,10 +1106,12 @@ static int launch_tti3d(const Plan &p, const StepConsts<float> &k, const TtiPara
     tti3d_chunks(p, a.nty * a.ntz * nshots, k.n0, 2 * p.L.R, 8, a.nchunk, a.xchunk);
     a.nshots = nshots, a.fwd = fwd;
     const int nb = a.nty * a.ntz * a.nchunk * nshots;
-    if (p.L.R == 2)
-        hipLaunchKernelGGL((tti3d_step_kernel<2>), dim3(nb), dim3(16 * TTI3D_TY), 0, p.stream, a);
-    else
-        hipLaunchKernelGGL((tti3d_step_kernel<4>), dim3(nb), dim3(16 * TTI3D_TY), 0, p.stream, a);
+    switch (p.L.R) {
+        case 2: hipLaunchKernelGGL((tti3d_step_kernel<2>), dim3(nb), dim3(16 * TTI3D_TY), 0, p.stream, a); break;
+        case 4: hipLaunchKernelGGL((tti3d_step_kernel<4>), dim3(nb), dim3(16 * TTI3D_TY), 0, p.stream, a); break;
+        case 6: hipLaunchKernelGGL((tti3d_step_wide_kernel<6>), dim3(nb), dim3(16 * TTI3D_TY), 0, p.stream, a); break;
+        default: hipLaunchKernelGGL((tti3d_step_wide_kernel<8>), dim3(nb), dim3(16 * TTI3D_TY), 0, p.stream, a);
+    }
     MIFWI_HIP(hipGetLastError());
     launches += 2;
     return MIFWI_OK;

@@ -1914,7 +1914,7 @@ static int tti_set_model(Plan &p, const void *eps, const void *delta, const void
         if ((rc = dev_alloc(p, &p.tti_adj, 2 * S * 3 * fb, true))) return rc;
         if ((rc = dev_alloc(p, &p.tti_tmp, 4 * S * fb, true))) return rc;
         // float32 3-D plans step with the two marching kernels when their tables fit beside everything else
-        if (p.L.ndim == 3 && sizeof(T) == 4 && p.L.R <= 4 && !(p.cfg.flags & MIFWI_FLAG_GENERIC) && !getenv("MIFWI_TTI3D_UNTILED")) {
+        if (p.L.ndim == 3 && sizeof(T) == 4 && p.L.R <= 8 && !(p.cfg.flags & MIFWI_FLAG_GENERIC) && !getenv("MIFWI_TTI3D_UNTILED")) {
             size_t free_b = 0, total_b = 0;
             if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && (2 * S + 2) * fb < free_b / 2) {
                 if ((rc = dev_alloc(p, &p.tti_gz3, 2 * S * fb, true))) return rc;

@@ -88,8 +88,8 @@ def test_tti_tiled_kernel_matches_untiled_and_oracle(mifwi, shape, so):
 
 @pytest.mark.parametrize("shape,so", [((40, 21, 70), 16), ((30, 19, 23), 12), ((25, 37, 131), 8), ((20, 18, 30), 4)])
 def test_tti_3d_marching_kernels_match_untiled_and_oracle(mifwi, shape, so):
-    """float32 3-D plans up to space order 8 step with the two marching kernels (ragged tiles in y and z, several
-    chunks of planes, two shots); higher orders and FLAG_GENERIC keep the kernels with one thread per point."""
+    """float32 3-D plans step with the marching kernels (every radius they are built for, ragged tiles in y and z,
+    several chunks of planes, two shots); FLAG_GENERIC keeps the kernels with one thread per point."""
     prob, vp, src0, rec0, rng = tti_case(shape, so=so, dtype=np.float32)
     dt, nt, nshots = float(prob.critical_dt), 40, 2
     dom = np.array([(n - 1) * 10. for n in shape])
