@@ -29,4 +29,19 @@ for _ in range(4):
     plan.tti_forward(w)
     best = min(best, plan.stats()["fwd_ms"] / (nt - 2))
 ng = float(np.prod(prob.shape_pad))
+if os.environ.get("PROBE_GRAD"):   # adjoint, saving forward, gradient and Born loops as well
+    d = plan.tti_forward(w)
+    t = {"adjoint": 1e9, "forward(save)": 1e9, "gradient": 1e9, "born": 1e9}
+    dm = np.zeros(prob.shape_pad, np.float32)
+    dm[60:90, 60:90, 60:90] = 0.01
+    for _ in range(3):
+        plan.tti_adjoint(d)
+        t["adjoint"] = min(t["adjoint"], plan.stats()["bwd_ms"] / (nt - 2))
+        plan.tti_forward(w, save=True)
+        t["forward(save)"] = min(t["forward(save)"], plan.stats()["fwd_ms"] / (nt - 2))
+        plan.tti_gradient(d)
+        t["gradient"] = min(t["gradient"], plan.stats()["bwd_ms"] / (nt - 2))
+        plan.tti_born(w, dm)
+        t["born"] = min(t["born"], plan.stats()["fwd_ms"] / (nt - 2))
+    print("  " + "  ".join("%s %.1f us/step" % (k, v * 1e3) for k, v in t.items()), flush=True)
 print("%s TTI 3-D %d^3 so=%d: %.1f us/step = %.1f Gpts/s" % (os.path.basename(os.environ.get("MIFWI_LIB", "libmifwi.so")), n + 80, so, best * 1e3, ng / best / 1e6), flush=True)
