@@ -524,7 +524,7 @@ def main():
                 "profile_avg_launch_us": prof_us,
                 "profile_frac": (g_bytes_loop / max(1, bwd_launches)) / (prof_us * 1e-6) / 1e9 / HBM_PEAK_GBS
                 if prof_us else None,
-                "profile": "profiles/r2_04_bench_kernel_stats.txt: rocprofv3 --kernel-trace of this command with --no-batches, mean over "
+                "profile": "profiles/r2_05_bench_kernel_stats.txt: rocprofv3 --kernel-trace of this command with --no-batches, mean over "
                            "the backward loop's launches (plain and two-step gradient launches weighted by count)",
                 "profile_note": "the tracer slows these ~5 us launches: HIP events around the same loop read 8.7 us "
                                 "per launch under rocprofv3 and 5.6 us without it (profiles/r2_01_bench_line_under_trace.json "
@@ -554,7 +554,7 @@ def main():
                          "kernel per step, while this kernel keeps the model, the two newest levels and the gradient sums "
                          "on chip for the whole loop and moves 13 (bytes_this_kernel_moves.frac is the fraction of the "
                          "HBM peak it really uses)",
-            "profile": "profiles/r2_04_bench_kernel_stats.txt: rocprofv3 --kernel-trace of this command with "
+            "profile": "profiles/r2_05_bench_kernel_stats.txt: rocprofv3 --kernel-trace of this command with "
                        "--no-batches, mean over the whole-loop launches of the gradient variant"})
         roofline.pop("profile_note", None)
     roofline_fwd = {"bound": "hbm", "achieved": f_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
