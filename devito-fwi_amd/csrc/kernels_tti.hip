@@ -634,9 +634,9 @@ __global__ __launch_bounds__(16 * TTI3D_TY) void tti3d_gz_kernel(Tti3DGzArgs a)
 // Second march: X = laplace(A) - Gzz(A), Y = Gzz(B) and the update of both fields.  Registers hold the planes
 // x - R .. x + R of A and the planes x - p .. x + p of the x products wx Gz of both fields.
 struct Tti3DArgs {
-    const float *A;            // stencilled field of shot 0 (forward: u; adjoint: et p + dl r)
+    const float *A, *B;        // stencilled fields of shot 0 (forward: u, v; adjoint: et p + dl r, dl p + r)
     long a_stride;
-    const float *gz;           // [2][shots][field]
+    const float *gz;           // [2][shots][field] (two marches)
     long gz_stride;
     const float *wx, *wy, *wz;
     const float *et, *dl, *m, *eta;
@@ -1035,6 +1035,313 @@ __global__ __launch_bounds__(16 * TTI3D_TY) void tti3d_step_wide_kernel(Tti3DArg
     }
 }
 
+// One march for radius 2 and 4: Gz is not stored at all.  In the iteration of plane x a thread forms Gz of both
+// fields at plane x + p for its own column (the x part of Gzz at plane x needs the products up to there; A's queue
+// reaches x + R = x + 2p, B gets a queue of 2p + 1 planes), pushes wx Gz into the x queues, and hands wy Gz and wz Gz
+// to its neighbours through LDS; 2p (TZ/4) + 2 TY threads of the block also form them for one column each of the halo
+// (p rows above and below the tile, one 16-byte piece left and right of every row), with their neighbours along x
+// loaded directly.  After the barrier every thread takes the y and z parts of Gzz at plane x + p from LDS into a
+// queue of p + 1 planes, and then updates plane x.  A chunk starts 2p planes early (no update there) so that the
+// queues are full at its first plane.  11 streams read and 2 written per step, against 19 and 4 with two marches.
+template <int R>
+__global__ __launch_bounds__(256) void tti3d_fused_kernel(Tti3DArgs a)
+{
+    constexpr int P = R / 2, TY = 16, TZ = 64, V = 4, TQ = TZ / V;
+    constexpr int HY = TY + 2 * P, WZ = TZ + 8;
+    constexpr int NHY = 2 * P * TQ, NHZ = 2 * TY, NH = NHY + NHZ;
+    static_assert(R == 2 || R == 4, "radius");
+    static_assert(NH <= 256, "halo columns");
+    __shared__ __attribute__((aligned(16))) float syA[2][HY * TZ], syB[2][HY * TZ], szA[2][TY * WZ], szB[2][TY * WZ];
+    int t = xcd_contiguous_block();
+    const int tile_z = t % a.ntz;
+    t /= a.ntz;
+    const int tile_y = t % a.nty;
+    t /= a.nty;
+    const int chunk = t % a.nchunk;
+    const int shot = t / a.nchunk;
+    const int xa = chunk * a.xchunk, xb = min(a.n0, xa + a.xchunk);
+    if (xa >= xb) return;
+    const int tid = threadIdx.x, ty = tid / TQ, tq = tid % TQ;
+    const int y0 = tile_y * TY, z0 = tile_z * TZ;
+    const int y = y0 + ty, z = z0 + V * tq;
+    const bool live = y < a.n1 && z < a.n2;              // points this thread updates
+    const bool liveg = y < a.n1 + P && z < a.n2 + P;     // columns whose Gz somebody needs
+    // lane offsets in bytes from point (x, -P, -4) of a plane; columns nobody needs read the tile's first column
+    const long s1 = a.s1;
+    const unsigned voff0 = (unsigned)(((long)(y0 + P) * s1 + z0 + 4) * 4);
+    const unsigned voff = liveg ? (unsigned)(((long)(y + P) * s1 + z + 4) * 4) : voff0;
+    const long org = a.off0 - (long)P * s1 - 4;
+    // the halo column of this thread (tid < NH): rows above / below the tile, then pieces left / right of each row
+    const bool hisy = tid < NHY;
+    int hy, hz, hl;   // grid row, first grid z, float index in sy (rows) or sz (pieces)
+    if (hisy) {
+        const int r = tid / TQ;
+        hy = r < P ? y0 - P + r : y0 + TY + (r - P);
+        hz = z0 + V * tq;
+        hl = (r < P ? r : TY + r) * TZ + V * tq;
+    } else {
+        const int k = tid - NHY, row = k >> 1, side = k & 1;
+        hy = y0 + row;
+        hz = side ? z0 + TZ : z0 - 4;
+        hl = row * WZ + (side ? TZ + 4 : 0);
+    }
+    const bool hrole = tid < NH;
+    const bool hlive = hrole && hy < a.n1 + P && hz < a.n2 + P;
+    const unsigned hvoff = hlive ? (unsigned)(((long)(hy + P) * s1 + hz + 4) * 4) : voff0;
+
+    const float *A = a.A + (long)shot * a.a_stride + org, *B = a.B + (long)shot * a.a_stride + org;
+    const float *wx = a.wx + org, *wy = a.wy + org, *wz = a.wz + org;
+    const long lv = (long)shot * a.lv_stride + org;
+
+    // qa[j]: A at plane x - R + j; qb[j]: B at plane x + j; qxa / qxb[j]: wx Gz at plane x - P + j;
+    // pa / pb[j]: y and z parts of the divergence of the products at plane x + j   (all after the shift)
+    tf4 qa[2 * R + 1], qb[2 * P + 1], qxa[2 * P + 1], qxb[2 * P + 1], pa[P + 1], pb[P + 1];
+    const int x0 = xa - 2 * P;
+#pragma unroll
+    for (int j = 0; j < 2 * R; ++j) gld<0>(qa[j + 1], voff, A + (long)max(x0 - R + j, -R) * a.s0);
+#pragma unroll
+    for (int j = 0; j < 2 * P; ++j) gld<0>(qb[j + 1], voff, B + (long)(x0 + j) * a.s0);
+    vm_wait<0>();
+#pragma unroll
+    for (int j = 1; j <= 2 * R; ++j) arrived(qa[j]);
+#pragma unroll
+    for (int j = 1; j <= 2 * P; ++j) arrived(qb[j]);
+#pragma unroll
+    for (int j = 0; j <= 2 * P; ++j) qxa[j] = qxb[j] = tf4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j <= P; ++j) pa[j] = pb[j] = tf4{0.f, 0.f, 0.f, 0.f};
+
+    for (int x = x0; x < xb; ++x) {
+        const int buf = (x - x0) & 1;
+        const long pg = (long)(x + P) * a.s0;   // the plane Gz is formed at
+        const float *Ag = A + pg, *Bg = B + pg;
+        {
+            // own column: new planes of the queues, rows and line of both fields at plane x + P, the three weights
+            tf4 na, nb, ya[2 * P], yb[2 * P], za[2], zb[2], w0, w1, w2;
+            gld<0>(na, voff, Ag + (long)P * a.s0);
+            gld<0>(nb, voff, Bg + (long)P * a.s0);
+#pragma unroll
+            for (int j = 1; j <= P; ++j) {
+                gld<0>(ya[2 * j - 2], voff, Ag - (long)j * s1);
+                gld<0>(ya[2 * j - 1], voff, Ag + (long)j * s1);
+                gld<0>(yb[2 * j - 2], voff, Bg - (long)j * s1);
+                gld<0>(yb[2 * j - 1], voff, Bg + (long)j * s1);
+            }
+            gld<-16>(za[0], voff, Ag);
+            gld<16>(za[1], voff, Ag);
+            gld<-16>(zb[0], voff, Bg);
+            gld<16>(zb[1], voff, Bg);
+            gld<0>(w0, voff, wx + pg);
+            gld<0>(w1, voff, wy + pg);
+            gld<0>(w2, voff, wz + pg);
+            vm_wait<0>();
+            arrived(na), arrived(nb), arrived(za[0]), arrived(za[1]), arrived(zb[0]), arrived(zb[1]);
+            arrived(w0), arrived(w1), arrived(w2);
+#pragma unroll
+            for (int j = 0; j < 2 * P; ++j) arrived(ya[j]), arrived(yb[j]);
+#pragma unroll
+            for (int j = 0; j < 2 * R; ++j) qa[j] = qa[j + 1];
+            qa[2 * R] = na;
+#pragma unroll
+            for (int j = 0; j < 2 * P; ++j) qb[j] = qb[j + 1];
+            qb[2 * P] = nb;
+            tf4 dxa = {0.f, 0.f, 0.f, 0.f}, dxb = dxa, dya = dxa, dyb = dxa, dza = dxa, dzb = dxa;
+#pragma unroll
+            for (int j = 1; j <= P; ++j) {
+                dxa += a.a1[j] * (qa[R + P + j] - qa[R + P - j]);
+                dxb += a.a1[j] * (qb[P + j] - qb[P - j]);
+                dya += a.a1[j] * (ya[2 * j - 1] - ya[2 * j - 2]);
+                dyb += a.a1[j] * (yb[2 * j - 1] - yb[2 * j - 2]);
+            }
+            float la[V + 8], lb[V + 8];
+#pragma unroll
+            for (int i = 0; i < V; ++i) {
+                la[i] = za[0][i], la[4 + i] = qa[R + P][i], la[8 + i] = za[1][i];
+                lb[i] = zb[0][i], lb[4 + i] = qb[P][i], lb[8 + i] = zb[1][i];
+            }
+#pragma unroll
+            for (int j = 1; j <= P; ++j)
+#pragma unroll
+                for (int i = 0; i < V; ++i) {
+                    dza[i] += a.a1[j] * (la[4 + i + j] - la[4 + i - j]);
+                    dzb[i] += a.a1[j] * (lb[4 + i + j] - lb[4 + i - j]);
+                }
+            const tf4 ga = -(w0 * (dxa * a.ih[0]) + w1 * (dya * a.ih[1]) + w2 * (dza * a.ih[2]));
+            const tf4 gb = -(w0 * (dxb * a.ih[0]) + w1 * (dyb * a.ih[1]) + w2 * (dzb * a.ih[2]));
+#pragma unroll
+            for (int j = 0; j < 2 * P; ++j) qxa[j] = qxa[j + 1], qxb[j] = qxb[j + 1];
+            qxa[2 * P] = w0 * ga, qxb[2 * P] = w0 * gb;
+            *reinterpret_cast<tf4 *>(&syA[buf][(ty + P) * TZ + V * tq]) = w1 * ga;
+            *reinterpret_cast<tf4 *>(&syB[buf][(ty + P) * TZ + V * tq]) = w1 * gb;
+            *reinterpret_cast<tf4 *>(&szA[buf][ty * WZ + 4 + V * tq]) = w2 * ga;
+            *reinterpret_cast<tf4 *>(&szB[buf][ty * WZ + 4 + V * tq]) = w2 * gb;
+        }
+        if (hrole) {
+            // halo column: nothing of it is in registers
+            tf4 xa4[2 * P], xb4[2 * P], ya[2 * P], yb[2 * P], za[3], zb[3], w0, w1, w2;
+#pragma unroll
+            for (int j = 1; j <= P; ++j) {
+                gld<0>(xa4[2 * j - 2], hvoff, Ag - (long)j * a.s0);
+                gld<0>(xa4[2 * j - 1], hvoff, Ag + (long)j * a.s0);
+                gld<0>(xb4[2 * j - 2], hvoff, Bg - (long)j * a.s0);
+                gld<0>(xb4[2 * j - 1], hvoff, Bg + (long)j * a.s0);
+            }
+#pragma unroll
+            for (int j = 1; j <= P; ++j) {
+                gld<0>(ya[2 * j - 2], hvoff, Ag - (long)j * s1);
+                gld<0>(ya[2 * j - 1], hvoff, Ag + (long)j * s1);
+                gld<0>(yb[2 * j - 2], hvoff, Bg - (long)j * s1);
+                gld<0>(yb[2 * j - 1], hvoff, Bg + (long)j * s1);
+            }
+            gld<-16>(za[0], hvoff, Ag);
+            gld<0>(za[1], hvoff, Ag);
+            gld<16>(za[2], hvoff, Ag);
+            gld<-16>(zb[0], hvoff, Bg);
+            gld<0>(zb[1], hvoff, Bg);
+            gld<16>(zb[2], hvoff, Bg);
+            gld<0>(w0, hvoff, wx + pg);
+            gld<0>(w1, hvoff, wy + pg);
+            gld<0>(w2, hvoff, wz + pg);
+            vm_wait<0>();
+#pragma unroll
+            for (int j = 0; j < 2 * P; ++j) arrived(xa4[j]), arrived(xb4[j]), arrived(ya[j]), arrived(yb[j]);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) arrived(za[c]), arrived(zb[c]);
+            arrived(w0), arrived(w1), arrived(w2);
+            tf4 dxa = {0.f, 0.f, 0.f, 0.f}, dxb = dxa, dya = dxa, dyb = dxa, dza = dxa, dzb = dxa;
+#pragma unroll
+            for (int j = 1; j <= P; ++j) {
+                dxa += a.a1[j] * (xa4[2 * j - 1] - xa4[2 * j - 2]);
+                dxb += a.a1[j] * (xb4[2 * j - 1] - xb4[2 * j - 2]);
+                dya += a.a1[j] * (ya[2 * j - 1] - ya[2 * j - 2]);
+                dyb += a.a1[j] * (yb[2 * j - 1] - yb[2 * j - 2]);
+            }
+            float la[V + 8], lb[V + 8];
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+#pragma unroll
+                for (int i = 0; i < V; ++i) la[4 * c + i] = za[c][i], lb[4 * c + i] = zb[c][i];
+#pragma unroll
+            for (int j = 1; j <= P; ++j)
+#pragma unroll
+                for (int i = 0; i < V; ++i) {
+                    dza[i] += a.a1[j] * (la[4 + i + j] - la[4 + i - j]);
+                    dzb[i] += a.a1[j] * (lb[4 + i + j] - lb[4 + i - j]);
+                }
+            const tf4 ga = -(w0 * (dxa * a.ih[0]) + w1 * (dya * a.ih[1]) + w2 * (dza * a.ih[2]));
+            const tf4 gb = -(w0 * (dxb * a.ih[0]) + w1 * (dyb * a.ih[1]) + w2 * (dzb * a.ih[2]));
+            const tf4 w = hisy ? w1 : w2;
+            float *da = hisy ? &syA[buf][hl] : &szA[buf][hl], *db = hisy ? &syB[buf][hl] : &szB[buf][hl];
+            *reinterpret_cast<tf4 *>(da) = w * ga;
+            *reinterpret_cast<tf4 *>(db) = w * gb;
+        }
+        __syncthreads();
+        {
+            // y and z parts of the divergence of the products at plane x + P
+            float la[V + 8], lb[V + 8];
+            const tf4 l0 = *reinterpret_cast<const tf4 *>(&szA[buf][ty * WZ + V * tq]);
+            const tf4 l1 = *reinterpret_cast<const tf4 *>(&szA[buf][ty * WZ + V * tq + 4]);
+            const tf4 l2 = *reinterpret_cast<const tf4 *>(&szA[buf][ty * WZ + V * tq + 8]);
+            const tf4 m0 = *reinterpret_cast<const tf4 *>(&szB[buf][ty * WZ + V * tq]);
+            const tf4 m1 = *reinterpret_cast<const tf4 *>(&szB[buf][ty * WZ + V * tq + 4]);
+            const tf4 m2 = *reinterpret_cast<const tf4 *>(&szB[buf][ty * WZ + V * tq + 8]);
+#pragma unroll
+            for (int i = 0; i < V; ++i) {
+                la[i] = l0[i], la[4 + i] = l1[i], la[8 + i] = l2[i];
+                lb[i] = m0[i], lb[4 + i] = m1[i], lb[8 + i] = m2[i];
+            }
+            tf4 sa = {0.f, 0.f, 0.f, 0.f}, sb = sa;
+#pragma unroll
+            for (int j = 1; j <= P; ++j) {
+                tf4 ta, tb;
+#pragma unroll
+                for (int i = 0; i < V; ++i) {
+                    ta[i] = a.a1[j] * (la[4 + i + j] - la[4 + i - j]) * a.ih[2];
+                    tb[i] = a.a1[j] * (lb[4 + i + j] - lb[4 + i - j]) * a.ih[2];
+                }
+                const tf4 yap = *reinterpret_cast<const tf4 *>(&syA[buf][(ty + P + j) * TZ + V * tq]);
+                const tf4 yam = *reinterpret_cast<const tf4 *>(&syA[buf][(ty + P - j) * TZ + V * tq]);
+                const tf4 ybp = *reinterpret_cast<const tf4 *>(&syB[buf][(ty + P + j) * TZ + V * tq]);
+                const tf4 ybm = *reinterpret_cast<const tf4 *>(&syB[buf][(ty + P - j) * TZ + V * tq]);
+                ta += a.a1[j] * (yap - yam) * a.ih[1];
+                tb += a.a1[j] * (ybp - ybm) * a.ih[1];
+                sa += ta, sb += tb;
+            }
+#pragma unroll
+            for (int j = 0; j < P; ++j) pa[j] = pa[j + 1], pb[j] = pb[j + 1];
+            pa[P] = sa, pb[P] = sb;
+        }
+        if (x < xa) continue;   // planes before the chunk only fill the queues
+        const long px = (long)x * a.s0;
+        const float *Ap = A + px;
+        tf4 lap;
+        {
+            tf4 yA[2 * R], zA[2];
+#pragma unroll
+            for (int k = 1; k <= R; ++k) {
+                gld<0>(yA[2 * k - 2], voff, Ap - (long)k * s1);
+                gld<0>(yA[2 * k - 1], voff, Ap + (long)k * s1);
+            }
+            gld<-16>(zA[0], voff, Ap);
+            gld<16>(zA[1], voff, Ap);
+            vm_wait<0>();
+#pragma unroll
+            for (int k = 0; k < 2 * R; ++k) arrived(yA[k]);
+            arrived(zA[0]), arrived(zA[1]);
+            const tf4 ac = qa[R];
+            lap = a.c0 * ac;
+            float line[V + 8];
+#pragma unroll
+            for (int i = 0; i < V; ++i) line[i] = zA[0][i], line[4 + i] = ac[i], line[8 + i] = zA[1][i];
+#pragma unroll
+            for (int k = 1; k <= R; ++k)
+#pragma unroll
+                for (int i = 0; i < V; ++i) lap[i] += a.cz[k] * (line[4 + i - k] + line[4 + i + k]);
+#pragma unroll
+            for (int k = 1; k <= R; ++k) lap += a.cy[k] * (yA[2 * k - 2] + yA[2 * k - 1]);
+#pragma unroll
+            for (int k = 1; k <= R; ++k) lap += a.cx[k] * (qa[R - k] + qa[R + k]);
+        }
+        tf4 sA = pa[0], sB = pb[0];
+#pragma unroll
+        for (int j = 1; j <= P; ++j) {
+            sA += a.a1[j] * (qxa[P + j] - qxa[P - j]) * a.ih[0];
+            sB += a.a1[j] * (qxb[P + j] - qxb[P - j]) * a.ih[0];
+        }
+        const tf4 X = lap + sA, Y = -sB;   // Gzz = -s
+        tf4 et, dl, mm, ee, uc, uo, vc, vo;
+        gld<0>(et, voff, a.et + org + px);
+        gld<0>(dl, voff, a.dl + org + px);
+        gld<0>(mm, voff, a.m + org + px);
+        gld<0>(ee, voff, a.eta + org + px);
+        gld<0>(uc, voff, a.ucur + lv + px);
+        gld<0>(uo, voff, a.uold + lv + px);
+        gld<0>(vc, voff, a.vcur + lv + px);
+        gld<0>(vo, voff, a.vold + lv + px);
+        vm_wait<0>();
+        arrived(et), arrived(dl), arrived(mm), arrived(ee), arrived(uc), arrived(uo), arrived(vc), arrived(vo);
+        const tf4 H0 = a.fwd ? et * X + dl * Y : X;
+        const tf4 Hz = a.fwd ? dl * X + Y : Y;
+        tf4 un, vn;
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+            const float ed = ee[i] * a.dt;
+            un[i] = (a.dt2 * H0[i] + 2.0f * mm[i] * uc[i] - mm[i] * uo[i] + ed * uc[i]) / (mm[i] + ed);
+            vn[i] = (a.dt2 * Hz[i] + 2.0f * mm[i] * vc[i] - mm[i] * vo[i] + ed * vc[i]) / (mm[i] + ed);
+        }
+        if (live) {
+            float *uo_p = a.uout + lv + px + voff / 4, *vo_p = a.vout + lv + px + voff / 4;
+            if (z + V - 1 < a.n2) {
+                *reinterpret_cast<tf4 *>(uo_p) = un;
+                *reinterpret_cast<tf4 *>(vo_p) = vn;
+            } else {
+                for (int i = 0; i < V; ++i)
+                    if (z + i < a.n2) uo_p[i] = un[i], vo_p[i] = vn[i];
+            }
+        }
+    }
+}
+
 // float32 3-D plans that could allocate the tables of the marches (p.tti_gz3, p.tti_w) take them.  (At radius 6
 // and 8 the batches of tti3d_step_kernel and the plane queues do not fit in 256 registers together; the compiler then
 // moves registers whose loads are still in flight and the results are wrong -- hence tti3d_step_wide_kernel.)
@@ -1070,7 +1377,9 @@ static int launch_tti3d(const Plan &p, const StepConsts<float> &k, const TtiPara
     float *gz = (float *)p.tti_gz3;
     const float *w = (const float *)p.tti_w;
     const long gstride = (long)p.cfg.max_shots * k.field;
-    {
+    static const bool two_pass = getenv("MIFWI_TTI3D_TWOPASS") != nullptr;
+    const bool fused = p.L.R <= 4 && !two_pass;
+    if (!fused) {
         Tti3DGzArgs g{};
         g.A = A, g.B = B, g.ab_stride = ab_stride, g.gz = gz, g.gz_stride = gstride;
         g.wx = w, g.wy = w + k.field, g.wz = q.ct;
@@ -1091,7 +1400,7 @@ static int launch_tti3d(const Plan &p, const StepConsts<float> &k, const TtiPara
         MIFWI_HIP(hipGetLastError());
     }
     Tti3DArgs a{};
-    a.A = A, a.a_stride = ab_stride, a.gz = gz, a.gz_stride = gstride;
+    a.A = A, a.B = B, a.a_stride = ab_stride, a.gz = gz, a.gz_stride = gstride;
     a.wx = w, a.wy = w + k.field, a.wz = q.ct;
     a.et = q.et, a.dl = q.dl, a.m = (const float *)p.m, a.eta = (const float *)p.eta;
     a.ucur = lv.ucur, a.uold = lv.uold, a.vcur = lv.vcur, a.vold = lv.vold, a.uout = lv.uout, a.vout = lv.vout;
@@ -1106,6 +1415,15 @@ static int launch_tti3d(const Plan &p, const StepConsts<float> &k, const TtiPara
     tti3d_chunks(p, a.nty * a.ntz * nshots, k.n0, 2 * p.L.R, 8, a.nchunk, a.xchunk);
     a.nshots = nshots, a.fwd = fwd;
     const int nb = a.nty * a.ntz * a.nchunk * nshots;
+    if (fused) {
+        if (p.L.R == 2)
+            hipLaunchKernelGGL((tti3d_fused_kernel<2>), dim3(nb), dim3(256), 0, p.stream, a);
+        else
+            hipLaunchKernelGGL((tti3d_fused_kernel<4>), dim3(nb), dim3(256), 0, p.stream, a);
+        MIFWI_HIP(hipGetLastError());
+        launches += 1;
+        return MIFWI_OK;
+    }
     switch (p.L.R) {
         case 2: hipLaunchKernelGGL((tti3d_step_kernel<2>), dim3(nb), dim3(16 * TTI3D_TY), 0, p.stream, a); break;
         case 4: hipLaunchKernelGGL((tti3d_step_kernel<4>), dim3(nb), dim3(16 * TTI3D_TY), 0, p.stream, a); break;
