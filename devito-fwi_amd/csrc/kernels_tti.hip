@@ -1275,6 +1275,7 @@ __global__ __launch_bounds__(256) void tti3d_fused_kernel(Tti3DArgs a)
         const long px = (long)x * a.s0;
         const float *Ap = A + px;
         tf4 lap;
+        tf4 et, dl, mm, ee, uc, uo, vc, vo;
         {
             tf4 yA[2 * R], zA[2];
 #pragma unroll
@@ -1284,7 +1285,15 @@ __global__ __launch_bounds__(256) void tti3d_fused_kernel(Tti3DArgs a)
             }
             gld<-16>(zA[0], voff, Ap);
             gld<16>(zA[1], voff, Ap);
-            vm_wait<0>();
+            gld<0>(et, voff, a.et + org + px);
+            gld<0>(dl, voff, a.dl + org + px);
+            gld<0>(mm, voff, a.m + org + px);
+            gld<0>(ee, voff, a.eta + org + px);
+            gld<0>(uc, voff, a.ucur + lv + px);
+            gld<0>(uo, voff, a.uold + lv + px);
+            gld<0>(vc, voff, a.vcur + lv + px);
+            gld<0>(vo, voff, a.vold + lv + px);
+            vm_wait<8>();
 #pragma unroll
             for (int k = 0; k < 2 * R; ++k) arrived(yA[k]);
             arrived(zA[0]), arrived(zA[1]);
@@ -1309,15 +1318,6 @@ __global__ __launch_bounds__(256) void tti3d_fused_kernel(Tti3DArgs a)
             sB += a.a1[j] * (qxb[P + j] - qxb[P - j]) * a.ih[0];
         }
         const tf4 X = lap + sA, Y = -sB;   // Gzz = -s
-        tf4 et, dl, mm, ee, uc, uo, vc, vo;
-        gld<0>(et, voff, a.et + org + px);
-        gld<0>(dl, voff, a.dl + org + px);
-        gld<0>(mm, voff, a.m + org + px);
-        gld<0>(ee, voff, a.eta + org + px);
-        gld<0>(uc, voff, a.ucur + lv + px);
-        gld<0>(uo, voff, a.uold + lv + px);
-        gld<0>(vc, voff, a.vcur + lv + px);
-        gld<0>(vo, voff, a.vold + lv + px);
         vm_wait<0>();
         arrived(et), arrived(dl), arrived(mm), arrived(ee), arrived(uc), arrived(uo), arrived(vc), arrived(vo);
         const tf4 H0 = a.fwd ? et * X + dl * Y : X;

@@ -1,5 +1,5 @@
-"""The marching 3-D TTI kernels (csrc/kernels_tti.hip: tti3d_gz_kernel, tti3d_step_kernel,
-tti3d_step_wide_kernel) issue their loads through
+"""The marching 3-D TTI kernels (csrc/kernels_tti.hip: tti3d_fused_kernel, tti3d_gz_kernel,
+tti3d_step_kernel, tti3d_step_wide_kernel) issue their loads through
 inline assembly and wait for them by hand; the compiler does not know that the destination registers are still being
 written.  This test compiles the file to gfx950 assembly and walks the kernels: between a load and the wait that
 covers it nothing may touch the load's registers (a register copy or spill placed there by the compiler would read
@@ -24,6 +24,7 @@ def test_no_instruction_touches_a_register_with_a_load_in_flight(tmp_path):
     asm = str(tmp_path / "kernels_tti.s")
     subprocess.check_call([HIPCC] + flags + ["--cuda-device-only", "-S", os.path.join(csrc, "kernels_tti.hip"), "-o", asm],
                           cwd=csrc, stderr=subprocess.DEVNULL)
-    bad, nfun = check_pending_regs.check_file(asm, ["tti3d_step_kernel", "tti3d_step_wide_kernel", "tti3d_gz_kernel"])
-    assert nfun == 8      # radius 2, 4 and 6, 8 (wide) of the step, p = 1 .. 4 of the Gz march
+    bad, nfun = check_pending_regs.check_file(asm, ["tti3d_fused_kernel", "tti3d_step_kernel", "tti3d_step_wide_kernel",
+                                                    "tti3d_gz_kernel"])
+    assert nfun == 10     # radius 2, 4 of the single march; 2, 4 and 6, 8 (wide) of the step, p = 1 .. 4 of the Gz march
     assert bad == 0
