@@ -1377,8 +1377,7 @@ static int launch_tti3d(const Plan &p, const StepConsts<float> &k, const TtiPara
     float *gz = (float *)p.tti_gz3;
     const float *w = (const float *)p.tti_w;
     const long gstride = (long)p.cfg.max_shots * k.field;
-    static const bool two_pass = getenv("MIFWI_TTI3D_TWOPASS") != nullptr;
-    const bool fused = p.L.R <= 4 && !two_pass;
+    const bool fused = p.L.R <= 4 && !p.tti_two_pass;
     if (!fused) {
         Tti3DGzArgs g{};
         g.A = A, g.B = B, g.ab_stride = ab_stride, g.gz = gz, g.gz_stride = gstride;

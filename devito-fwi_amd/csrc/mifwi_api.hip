@@ -1937,6 +1937,7 @@ static int tti_set_model(Plan &p, const void *eps, const void *delta, const void
         }
         if ((rc = launch_tti_param<T>(p, k, src, par + (long)f * p.L.field, spec[f].mode, spec[f].halo))) return rc;
     }
+    p.tti_two_pass = getenv("MIFWI_TTI3D_TWOPASS") != nullptr;
     if (p.tti_w && (rc = launch_tti3d_weights(p))) return rc;
     if (p.tti_ck_K > 0) p.tti_save_valid = false;   // checkpoints belong to the parameters they were taken with
     return finish(p);   // wavefields of earlier runs stay readable: they are not touched here

@@ -137,6 +137,7 @@ struct Plan {
     // 3-D float32 plans: Gz of the two stencilled fields, [2][max_shots][field], and the tables st cp, st sp, [2][field]
     // (kernels_tti.hip::tti3d_gz_kernel / tti3d_step_kernel)
     void *tti_gz3 = nullptr, *tti_w = nullptr;
+    bool tti_two_pass = false;   // orders 4 and 8 with two marches as well (MIFWI_TTI3D_TWOPASS at tti_set_model)
     bool tti_fwd_valid = false, tti_adj_valid = false;
     // host copies of the coordinates last given to mifwi_set_geometry (the sparse tables depend on the tile
     // shape, which the first mifwi_tti_set_model may change)

@@ -87,7 +87,7 @@ def test_tti_tiled_kernel_matches_untiled_and_oracle(mifwi, shape, so):
 
 
 @pytest.mark.parametrize("shape,so", [((40, 21, 70), 16), ((30, 19, 23), 12), ((25, 37, 131), 8), ((20, 18, 30), 4)])
-def test_tti_3d_marching_kernels_match_untiled_and_oracle(mifwi, shape, so):
+def test_tti_3d_marching_kernels_match_untiled_and_oracle(mifwi, monkeypatch, shape, so):
     """float32 3-D plans step with the marching kernels (every radius they are built for, ragged tiles in y and z,
     several chunks of planes, two shots); FLAG_GENERIC keeps the kernels with one thread per point."""
     prob, vp, src0, rec0, rng = tti_case(shape, so=so, dtype=np.float32)
@@ -97,18 +97,28 @@ def test_tti_3d_marching_kernels_match_untiled_and_oracle(mifwi, shape, so):
     rec = ((rng.random((nshots, 7, 3)) * 0.9 + 0.05) * dom).astype(np.float32)
     w = (orc.ricker(0.03, dt * np.arange(nt))[None, :, None] * (1 + np.arange(nshots))[:, None, None]).astype(np.float32)
     out = {}
-    for name, flags in (("march", 0), ("untiled", mifwi.FLAG_GENERIC)):
+    variants = [("march", 0, None), ("untiled", mifwi.FLAG_GENERIC, None)]
+    if so <= 8:   # these orders take one march by default; the two-march form of the same orders is kept as well
+        variants.append(("two marches", 0, "1"))
+    for name, flags, two_pass in variants:
         plan = mifwi.Plan(prob.shape_pad, prob.spacing, prob.origin_pad, so, nt, dt, 1, 7, max_shots=nshots,
                           dtype=np.float32, flags=flags)
         plan.set_model(prob.vp, prob.damp)
+        if two_pass:
+            monkeypatch.setenv("MIFWI_TTI3D_TWOPASS", two_pass)   # read by tti_set_model
         plan.tti_set_model(prob.epsilon, prob.delta, prob.theta, prob.phi)
+        monkeypatch.delenv("MIFWI_TTI3D_TWOPASS", raising=False)
         plan.set_geometry(src, rec, rec_per_shot=True)
         d = plan.tti_forward(w, wavelet_per_shot=True)
         a = plan.tti_adjoint(d)
         out[name] = (d, a, plan.read_wavefield(3, shot=1), plan.read_wavefield(6, shot=0))
         plan.close()
-    for x, y in zip(out["march"], out["untiled"]):
-        assert np.abs(y).max() > 0 and rel_l2(x, y) <= 5e-5   # float32 rounding (different contraction)
+    for name in out:
+        if name != "untiled":
+            for x, y in zip(out[name], out["untiled"]):
+                assert np.abs(y).max() > 0 and rel_l2(x, y) <= 5e-5   # float32 rounding (different contraction)
+    if "two marches" in out:   # and the two forms do differ in rounding, i.e. both really ran
+        assert any(not np.array_equal(x, y) for x, y in zip(out["march"], out["two marches"]))
     ref = prob.forward(src[1], w[1], rec[1], dt=dt)
     assert rel_l2(out["march"][0][1], ref) <= 2e-5
     assert rel_l2(out["march"][1][1], prob.adjoint(src[1], rec[1], ref, dt=dt)) <= 1e-4
