@@ -509,6 +509,12 @@ __device__ inline void gld(tf4 &v, unsigned voff, const float *sbase)
 {
     asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(v) : "v"(voff), "s"(sbase), "n"(OFF) : "memory");
 }
+// the same load marked non-temporal: a stream that is read once and should not displace the lines tiles share
+template <int OFF>
+__device__ inline void gld_nt(tf4 &v, unsigned voff, const float *sbase)
+{
+    asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3 nt" : "=v"(v) : "v"(voff), "s"(sbase), "n"(OFF) : "memory");
+}
 template <int N>
 __device__ inline void vm_wait()
 {
@@ -1285,14 +1291,14 @@ __global__ __launch_bounds__(256) void tti3d_fused_kernel(Tti3DArgs a)
             }
             gld<-16>(zA[0], voff, Ap);
             gld<16>(zA[1], voff, Ap);
-            gld<0>(et, voff, a.et + org + px);
-            gld<0>(dl, voff, a.dl + org + px);
-            gld<0>(mm, voff, a.m + org + px);
-            gld<0>(ee, voff, a.eta + org + px);
+            gld_nt<0>(et, voff, a.et + org + px);
+            gld_nt<0>(dl, voff, a.dl + org + px);
+            gld_nt<0>(mm, voff, a.m + org + px);
+            gld_nt<0>(ee, voff, a.eta + org + px);
             gld<0>(uc, voff, a.ucur + lv + px);
-            gld<0>(uo, voff, a.uold + lv + px);
+            gld_nt<0>(uo, voff, a.uold + lv + px);
             gld<0>(vc, voff, a.vcur + lv + px);
-            gld<0>(vo, voff, a.vold + lv + px);
+            gld_nt<0>(vo, voff, a.vold + lv + px);
             vm_wait<8>();
 #pragma unroll
             for (int k = 0; k < 2 * R; ++k) arrived(yA[k]);
@@ -1332,8 +1338,8 @@ __global__ __launch_bounds__(256) void tti3d_fused_kernel(Tti3DArgs a)
         if (live) {
             float *uo_p = a.uout + lv + px + voff / 4, *vo_p = a.vout + lv + px + voff / 4;
             if (z + V - 1 < a.n2) {
-                *reinterpret_cast<tf4 *>(uo_p) = un;
-                *reinterpret_cast<tf4 *>(vo_p) = vn;
+                __builtin_nontemporal_store(un, reinterpret_cast<tf4 *>(uo_p));
+                __builtin_nontemporal_store(vn, reinterpret_cast<tf4 *>(vo_p));
             } else {
                 for (int i = 0; i < V; ++i)
                     if (z + i < a.n2) uo_p[i] = un[i], vo_p[i] = vn[i];
