@@ -486,13 +486,17 @@ static int launch_tti_step_r(const Plan &p, const StepConsts<T> &k, const TtiPar
 }
 
 // ------------------------------------------------------------------------------------------------
-// 3-D float32 TTI step as two marches along x (the arithmetic of tti_gz_kernel + tti_step_kernel).  A 256-thread
+// 3-D float32 TTI step as marches along x (the arithmetic of tti_gz_kernel + tti_step_kernel).  A 256-thread
 // block owns a 16 x 64 tile of the (y, z) plane and a chunk of planes; a thread owns four consecutive z points of
 // one row and keeps the planes it needs again along x in registers.  The y and z neighbours come straight from
 // memory as aligned 16-byte loads -- rows y +- j, and the neighbouring pieces of the z line -- which neighbouring
-// threads of the block request at the same time: no LDS, no barrier.  Stores cost about twice what loads cost on
-// this part, so the first march stores Gz of the two fields only and the second forms the products with the
-// direction cosines (wx = st cp and wy = st sp, tabulated once per model; wz = ct) at the neighbouring points itself.
+// threads of the block request at the same time.
+//   Two marches (tti3d_gz_kernel, then tti3d_step_kernel or tti3d_step_wide_kernel; space orders 12 and 16, and 4
+// and 8 on request): no LDS, no barrier.  Stores cost about twice what loads cost on this part, so the first march
+// stores Gz of the two fields only and the second forms the products with the direction cosines (wx = st cp and
+// wy = st sp, tabulated once per model; wz = ct) at the neighbouring points itself.
+//   One march (tti3d_fused_kernel; space orders 4 and 8): Gz is formed a few planes ahead of the update and handed to
+// the neighbouring threads through LDS, never stored.
 // ------------------------------------------------------------------------------------------------
 #ifndef TTI3D_TY
 #define TTI3D_TY 16   // rows of a tile of the marching kernels (16 threads of four points per row)
