@@ -1357,7 +1357,8 @@ __global__ __launch_bounds__(256) void tti3d_fused_kernel(Tti3DArgs a)
 // moves registers whose loads are still in flight and the results are wrong -- hence tti3d_step_wide_kernel.)
 static bool tti3d_available(const Plan &p)
 {
-    return p.L.ndim == 3 && p.esize == 4 && p.tti_gz3 && p.tti_w && !(p.cfg.flags & MIFWI_FLAG_GENERIC) &&
+    const bool one_march = p.L.R <= 4 && !p.tti_two_pass;   // needs no stored Gz
+    return p.L.ndim == 3 && p.esize == 4 && p.tti_w && (one_march || p.tti_gz3) && !(p.cfg.flags & MIFWI_FLAG_GENERIC) &&
            p.L.R % 2 == 0 && p.L.R <= 8;
 }
 

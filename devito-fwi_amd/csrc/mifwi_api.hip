@@ -1913,13 +1913,17 @@ static int tti_set_model(Plan &p, const void *eps, const void *delta, const void
         if ((rc = dev_alloc(p, &p.tti_fwd, 2 * S * 3 * fb, true))) return rc;
         if ((rc = dev_alloc(p, &p.tti_adj, 2 * S * 3 * fb, true))) return rc;
         if ((rc = dev_alloc(p, &p.tti_tmp, 4 * S * fb, true))) return rc;
-        // float32 3-D plans step with the two marching kernels when their tables fit beside everything else
-        if (p.L.ndim == 3 && sizeof(T) == 4 && p.L.R <= 8 && !(p.cfg.flags & MIFWI_FLAG_GENERIC) && !getenv("MIFWI_TTI3D_UNTILED")) {
-            size_t free_b = 0, total_b = 0;
-            if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && (2 * S + 2) * fb < free_b / 2) {
-                if ((rc = dev_alloc(p, &p.tti_gz3, 2 * S * fb, true))) return rc;
-                if ((rc = dev_alloc(p, &p.tti_w, 2 * fb, true))) return rc;
-            }
+    }
+    // float32 3-D plans step with the marching kernels when their tables fit beside everything else: the direction
+    // cosine products (2 fields) and, for the form with two marches, Gz of both fields of every shot
+    p.tti_two_pass = getenv("MIFWI_TTI3D_TWOPASS") != nullptr;
+    if (p.L.ndim == 3 && sizeof(T) == 4 && p.L.R <= 8 && !(p.cfg.flags & MIFWI_FLAG_GENERIC) && !getenv("MIFWI_TTI3D_UNTILED")) {
+        const bool need_gz = p.L.R > 4 || p.tti_two_pass;
+        const size_t want = (p.tti_w ? 0 : 2 * fb) + (need_gz && !p.tti_gz3 ? 2 * S * fb : 0);
+        size_t free_b = 0, total_b = 0;
+        if (want && hipMemGetInfo(&free_b, &total_b) == hipSuccess && want < free_b / 2) {
+            if (!p.tti_w && (rc = dev_alloc(p, &p.tti_w, 2 * fb, true))) return rc;
+            if (need_gz && !p.tti_gz3 && (rc = dev_alloc(p, &p.tti_gz3, 2 * S * fb, true))) return rc;
         }
     }
     const StepConsts<T> k = make_consts<T>(p);
@@ -1937,7 +1941,6 @@ static int tti_set_model(Plan &p, const void *eps, const void *delta, const void
         }
         if ((rc = launch_tti_param<T>(p, k, src, par + (long)f * p.L.field, spec[f].mode, spec[f].halo))) return rc;
     }
-    p.tti_two_pass = getenv("MIFWI_TTI3D_TWOPASS") != nullptr;
     if (p.tti_w && (rc = launch_tti3d_weights(p))) return rc;
     if (p.tti_ck_K > 0) p.tti_save_valid = false;   // checkpoints belong to the parameters they were taken with
     return finish(p);   // wavefields of earlier runs stay readable: they are not touched here
