@@ -215,6 +215,14 @@ __global__ __launch_bounds__(256) void tti2d_kernel(Tti2DArgs a)
     __shared__ float cgA[HE * WE], sgA[HE * WE], cgB[HE * WE], sgB[HE * WE];
     __shared__ float acc[TX * TZ];
 
+    // Everything the first loads of a block need is fetched from the kernel arguments in one batch: left to be taken
+    // where they are used, behind the branches of the block's role and of the tile decoding, the arguments came in
+    // seven dependent steps, each with a wait of its own, before the first vector load went out.
+    asm volatile("" ::"s"(a.pt_idx), "s"(a.pt_w), "s"(a.itp_npoint), "s"(a.itp_per_shot), "s"(a.nshots), "s"(a.ntz),
+                 "s"(a.ntx), "s"(a.shot_stride), "s"(a.ucur), "s"(a.vcur), "s"(a.uold), "s"(a.vold), "s"(a.inj_per_shot),
+                 "s"(a.slot_count));
+    asm volatile("" ::"s"(a.n1), "s"(a.n2), "s"(a.off0), "s"(a.s1), "s"(a.m), "s"(a.eta), "s"(a.et), "s"(a.dl), "s"(a.ct),
+                 "s"(a.st));
     const int tid = threadIdx.x;
     const int nitp_blocks = a.pt_idx ? ((a.itp_npoint + NT - 1) / NT) * a.nshots : 0;
     int bid = blockIdx.x;
