@@ -173,6 +173,13 @@ __global__ __launch_bounds__(TX *TZ / V, V == 2 ? MIFWI_2D_V2_BLOCKS : ((XMODE =
     __shared__ __attribute__((aligned(16))) float lds[(TX + 2 * R) * P];
     __shared__ __attribute__((aligned(16))) float acc[TX * TZ];   // injected terms of this tile
 
+    // Everything the first loads of a block need is fetched from the kernel arguments in one batch: left to be taken
+    // where they are used, behind the branches of the block's role and of the tile decoding, the arguments come in
+    // half a dozen dependent steps, each with a wait of its own, before the first vector load goes out.
+    asm volatile("" ::"s"(a.pt_idx), "s"(a.pt_w), "s"(a.itp_npoint), "s"(a.itp_per_shot), "s"(a.nshots), "s"(a.shot0),
+                 "s"(a.ntz), "s"(a.ntx), "s"(a.shot_stride), "s"(a.cur), "s"(a.old), "s"(a.out), "s"(a.inj_per_shot),
+                 "s"(a.slot_count));
+    asm volatile("" ::"s"(a.n1), "s"(a.n2), "s"(a.off0), "s"(a.s1), "s"(a.m), "s"(a.eta));
     const int tid = threadIdx.x;
     const int nitp_blocks = a.pt_idx ? ((a.itp_npoint + NT - 1) / NT) * a.nshots : 0;
     int bid = blockIdx.x;
