@@ -1,7 +1,7 @@
 """GPU probe: per-step time of the 3-D float32 TTI forward loop (256^3 + 2 x 40 of sponge by default, one shot)."""
 import os, sys
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "devito-fwi_amd"), os.path.join(ROOT, "tests")]
 import mifwi
 from helpers import smooth_random_vp
