@@ -1,5 +1,7 @@
+"""GPU probe: margins of the golden-vector tests (worst relative error against the oracle per case)."""
 import sys, os
-sys.path[:0] = ["/root/repo", "/root/repo/devito-fwi_amd", "/root/repo/tests"]
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "devito-fwi_amd"), os.path.join(ROOT, "tests")]
 import numpy as np
 import test_gpu_golden as t
 from helpers import rel_l2
