@@ -217,7 +217,6 @@ __global__ __launch_bounds__(TX *TZ / V, V == 2 ? MIFWI_2D_V2_BLOCKS : ((XMODE =
 
     // ---- issue every global load up front: they share one memory round trip -------------------
     const int inj_tab = a.inj_per_shot ? shot : 0;
-    const int ninj = a.slot_count ? a.slot_count[(long)inj_tab * (a.ntx * a.ntz) + tile] : 0;  // block-uniform
     float4 stage[NSTAGE];
 #pragma unroll
     for (int i = 0; i < NSTAGE; ++i) {
@@ -265,7 +264,10 @@ __global__ __launch_bounds__(TX *TZ / V, V == 2 ? MIFWI_2D_V2_BLOCKS : ((XMODE =
     }
 
     // ---- injected terms of the cells this tile owns (rare: block-uniform branch): the terms were
-    // formed before the time loop, so both loads are independent of everything else in flight
+    // formed before the time loop, so both loads are independent of everything else in flight.  The count is the
+    // last load issued: it comes back as a vector load whose value every lane waits for, and ahead of the others
+    // that wait held them back.
+    const int ninj = a.slot_count ? a.slot_count[(long)inj_tab * (a.ntx * a.ntz) + tile] : 0;  // block-uniform
     if (ninj > 0) {
 #pragma unroll
         for (int i = 0; i < V; ++i) acc[V * tid + i] = 0.f;
