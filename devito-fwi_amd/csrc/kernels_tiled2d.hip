@@ -267,7 +267,10 @@ __global__ __launch_bounds__(TX *TZ / V, V == 2 ? MIFWI_2D_V2_BLOCKS : ((XMODE =
     // formed before the time loop, so both loads are independent of everything else in flight.  The count is the
     // last load issued: it comes back as a vector load whose value every lane waits for, and ahead of the others
     // that wait held them back.
-    const int ninj = a.slot_count ? a.slot_count[(long)inj_tab * (a.ntx * a.ntz) + tile] : 0;  // block-uniform
+    // read through the constant address space: a scalar load, whose wait does not hold vector loads back (the table is
+    // written before the launch; behind the `asm` above the compiler no longer proves that by itself)
+    typedef const __attribute__((address_space(4))) int32_t *ConstI32;
+    const int ninj = a.slot_count ? ((ConstI32)(unsigned long)a.slot_count)[(long)inj_tab * (a.ntx * a.ntz) + tile] : 0;   // block-uniform
     if (ninj > 0) {
 #pragma unroll
         for (int i = 0; i < V; ++i) acc[V * tid + i] = 0.f;

@@ -250,7 +250,10 @@ __global__ __launch_bounds__(256) void tti2d_kernel(Tti2DArgs a)
     const long sbase = (long)shot * a.shot_stride;
     const float *ucur = a.ucur + sbase, *vcur = a.vcur + sbase;
     const int inj_tab = a.inj_per_shot ? shot : 0;
-    const int ninj = a.slot_count ? a.slot_count[(long)inj_tab * (a.ntx * a.ntz) + tile] : 0;   // block-uniform
+    // read through the constant address space: a scalar load, whose wait does not hold vector loads back (the table is
+    // written before the launch; behind the `asm` above the compiler no longer proves that by itself)
+    typedef const __attribute__((address_space(4))) int32_t *ConstI32;
+    const int ninj = a.slot_count ? ((ConstI32)(unsigned long)a.slot_count)[(long)inj_tab * (a.ntx * a.ntz) + tile] : 0;   // block-uniform
 
     // ---- this thread's points: start their loads first ----------------------------------------------
     const int tz = tid & (TZ - 1);
