@@ -1891,11 +1891,12 @@ static int tti_set_model(Plan &p, const void *eps, const void *delta, const void
     if (p.kind == 1 && !p.tti_par && !getenv("MIFWI_2D_TX")) {
         // The TTI kernel holds two fields and four product arrays of a tile in LDS, so it runs best on small
         // tiles: 8 x 32 was the fastest shape at space orders up to 8 for every batch size, and at higher
-        // orders whenever the batch leaves the GPU under-filled (measured on MI355X, Marmousi-II grid: 2 shots
-        // at order 8 10.1 -> 6.4 us per step, at order 16 12.8 -> 8.8; 8 shots at order 16 17.0 -> 18.6, hence
-        // the condition).  The acoustic kernels of the same plan lose <= 3 % on that shape.
+        // orders up to about three 32 x 32 tiles per CU (measured on MI355X, Marmousi-II grid: 2 shots at
+        // order 8 10.1 -> 6.4 us per step, at order 16 12.8 -> 8.8; at order 16 8 shots 15.8 -> 15.2, 16 shots
+        // 25.1 -> 25.9, 32 shots 41.9 -> 48.1, hence the condition).  The acoustic kernels of the same plan lose
+        // <= 3 % on that shape.
         const int t32 = ((p.L.n[1] + 31) / 32) * ((p.L.n[2] + 31) / 32);
-        if ((p.L.R <= 4 || (long)p.cfg.max_shots * t32 <= 2L * p.ncu) && !(p.tile_tx == 8 && p.tile_tz == 32)) {
+        if ((p.L.R <= 4 || 8L * p.cfg.max_shots * t32 <= 25L * p.ncu) && !(p.tile_tx == 8 && p.tile_tz == 32)) {
             clear_graphs(p);
             p.tile_tx = 8, p.tile_tz = 32;
             p.ntx = (p.L.n[1] + 7) / 8, p.ntz = (p.L.n[2] + 31) / 32;

@@ -86,6 +86,34 @@ def test_tti_tiled_kernel_matches_untiled_and_oracle(mifwi, shape, so):
         assert rel_l2(out["tiled"][1][s], prob.adjoint(src[s], rec[s], ref, dt=dt)) <= 1e-4
 
 
+@pytest.mark.parametrize("tx", ["32", "16"])
+def test_tti_tiled_kernel_on_the_large_tiles(mifwi, monkeypatch, tx):
+    """Large batches at high space orders keep the 32-row (or 16 x 64) tiles of the acoustic kernels for the TTI
+    kernel; small test grids never reach that rule, so the tile height is pinned here (MIFWI_2D_TX also keeps
+    tti_set_model from re-tiling the plan)."""
+    monkeypatch.setenv("MIFWI_2D_TX", tx)
+    shape, so = (70, 48), 16
+    prob, vp, src0, rec0, rng = tti_case(shape, so=so, dtype=np.float32)
+    dt, nt, nshots = float(prob.critical_dt), 60, 2
+    dom = np.array([(n - 1) * 10. for n in shape])
+    src = ((rng.random((nshots, 1, 2)) * 0.5 + 0.25) * dom).astype(np.float32)
+    rec = ((rng.random((nshots, 9, 2)) * 0.9 + 0.05) * dom).astype(np.float32)
+    w = (orc.ricker(0.03, dt * np.arange(nt))[None, :, None] * (1 + np.arange(nshots))[:, None, None]).astype(np.float32)
+    out = {}
+    for name, flags in (("tiled", 0), ("untiled", mifwi.FLAG_GENERIC)):
+        plan = mifwi.Plan(prob.shape_pad, prob.spacing, prob.origin_pad, so, nt, dt, 1, 9, max_shots=nshots,
+                          dtype=np.float32, flags=flags)
+        plan.set_model(prob.vp, prob.damp)
+        plan.tti_set_model(prob.epsilon, prob.delta, prob.theta, prob.phi)
+        plan.set_geometry(src, rec, rec_per_shot=True)
+        d = plan.tti_forward(w, wavelet_per_shot=True)
+        out[name] = (d, plan.tti_adjoint(d), plan.read_wavefield(3, shot=1))
+        plan.close()
+    for x, y in zip(out["tiled"], out["untiled"]):
+        assert np.abs(y).max() > 0 and rel_l2(x, y) <= 5e-5
+    assert rel_l2(out["tiled"][0][0], prob.forward(src[0], w[0], rec[0], dt=dt)) <= 2e-5
+
+
 @pytest.mark.parametrize("shape,so", [((40, 21, 70), 16), ((30, 19, 23), 12), ((25, 37, 131), 8), ((20, 18, 30), 4)])
 def test_tti_3d_marching_kernels_match_untiled_and_oracle(mifwi, monkeypatch, shape, so):
     """float32 3-D plans step with the marching kernels (every radius they are built for, ragged tiles in y and z,
