@@ -45,12 +45,31 @@ def pmc_traffic(kernel):
     return _profile_entry(kernel).get("bytes")
 
 
+PROFILE_FILES = ("r3_traffic.json", "r2_traffic.json")    # newest first
+
+
 def _profile_entry(kernel):
-    try:
-        with open(os.path.join(ROOT, "profiles", "r2_traffic.json")) as f:
-            return json.load(f).get(kernel, {})
-    except (OSError, ValueError):
-        return {}
+    for name in PROFILE_FILES:
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                return dict(json.load(f).get(kernel, {}), source="profiles/" + name)
+        except (OSError, ValueError):
+            continue
+    return {}
+
+
+def exchange_floor_us():
+    """Cost of one step of the whole-loop kernel's neighbour exchange alone (counters, halo ring from the XCD's L2,
+    tile store, acknowledgement; no stencil, no saved level), measured by tools/micro/xcdsync.hip on this part and
+    recorded in profiles/: the bound of that kernel."""
+    for name in ("r3_exchange_floor.json", "r2_exchange_floor.json"):
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                d = json.load(f)
+                return float(d["us_per_step"]), "profiles/" + name
+        except (OSError, ValueError, KeyError):
+            continue
+    return None, None
 
 
 def profile_launch_us(kernel):
@@ -534,29 +553,37 @@ def main():
                             "gradient terms of both (mode 4); launch time, bytes and traffic are means over the loop"}
     whole_loop = st["bwd_kernel"].startswith("persist2d")
     if whole_loop:
-        # One launch runs the whole backward loop with the model, the two newest levels and the gradient sums of a
-        # tile resident in registers / LDS: per point and step it still has to read the saved forward level (4 B),
-        # write the new level for its neighbours (4 B) and read the halo ring (ring / tile = 1.25 -> 5 B).
-        moved = 13.0 * ngrid * per_gpu * steps_per_loop
-        roofline.update({
+        # One launch runs the whole backward loop; the model, the two newest levels and the gradient sums of a tile
+        # stay in registers / LDS, so the bytes a kernel per step must move are not moved and HBM is not what
+        # binds.  What binds is the chain of trips to the XCD's L2 that every step makes to exchange halos with the
+        # neighbouring tiles.  The roofline is therefore a latency one: time per step against the measured cost of
+        # that exchange alone.
+        floor_us, floor_src = exchange_floor_us()
+        step_us = bwd_ms * 1e3 / steps_per_loop
+        tr = _profile_entry(st["bwd_kernel"])
+        roofline = {
+            "bound": "xcd_l2_exchange_latency",
+            "achieved": 1.0 / step_us, "peak": (1.0 / floor_us) if floor_us else None, "unit": "time steps/us",
+            "frac": (floor_us / step_us) if floor_us else None,
+            "traffic": tr.get("bytes"),
+            "kernel": st["bwd_kernel"], "launches_per_loop": bwd_launches, "steps_per_launch": steps_per_loop,
+            "us_per_step": step_us, "exchange_floor_us_per_step": floor_us, "exchange_floor_source": floor_src,
+            "avg_launch_us": bwd_ms * 1e3 / max(1, bwd_launches),
             "timing": "HIP events around the backward time loop on the plan's stream (one launch runs the whole loop)",
+            "profile_avg_launch_us": prof_us,
+            "profile": "%s: rocprofv3 --kernel-trace of this command with --no-batches, mean over the whole-loop "
+                       "launches of the gradient variant" % tr.get("source"),
             "schedule": "one launch per loop: every tile keeps a block resident and synchronises with its neighbours "
                         "through per-tile counters in the L2 of the XCD that holds the shot",
-            "steps_per_launch": steps_per_loop, "us_per_step": bwd_ms * 1e3 / steps_per_loop,
-            "bytes_this_kernel_moves": {"per_point_and_step": 13.0, "achieved": moved / (bwd_ms * 1e-3) / 1e9,
-                                        "frac": moved / (bwd_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                        "what": "saved forward level read + new level written + halo ring read; "
-                                                "`achieved` and `frac` above price the step at the 32 B per point "
-                                                "that a kernel per step has to move"},
-            "bound_note": "the loop is bound by the neighbour synchronisation of each step (1.6 us per step for the "
-                          "exchange alone, tools/micro/xcdsync.hip), not by HBM",
-            "frac_note": "`frac` can exceed 1: `achieved` prices every step at the 32 algorithmic bytes per point of a "
-                         "kernel per step, while this kernel keeps the model, the two newest levels and the gradient sums "
-                         "on chip for the whole loop and moves 13 (bytes_this_kernel_moves.frac is the fraction of the "
-                         "HBM peak it really uses)",
-            "profile": "profiles/r2_05_bench_kernel_stats.txt: rocprofv3 --kernel-trace of this command with "
-                       "--no-batches, mean over the whole-loop launches of the gradient variant"})
-        roofline.pop("profile_note", None)
+            "hbm": {"bytes_counter": tr.get("bytes"),
+                    "achieved_GBps": (tr["bytes"] / (bwd_ms * 1e-3) / 1e9) if tr.get("bytes") else None,
+                    "frac": (tr["bytes"] / (bwd_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if tr.get("bytes") else None,
+                    "peak_GBps": HBM_PEAK_GBS,
+                    "what": "fabric-side bytes of one launch from the PMC passes (2 x FETCH_SIZE + WRITE_SIZE) over "
+                            "the launch time measured here: the saved forward field read once"},
+            "algorithmic_equivalent_GBps": g_ach,
+            "algorithmic_equivalent_note": "32 B per point update (what a kernel per step has to move) x points x steps "
+                                           "/ loop time; not a fraction of anything this kernel is bound by"}
     roofline_fwd = {"bound": "hbm", "achieved": f_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": f_ach / HBM_PEAK_GBS, "traffic": pmc_traffic(st["fwd_kernel"]), "kernel": st["fwd_kernel"],
                     "launches_per_loop": fwd_launches, "avg_launch_us": fwd_ms * 1e3 / max(1, fwd_launches),

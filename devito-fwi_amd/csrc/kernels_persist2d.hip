@@ -20,6 +20,13 @@
 // Arithmetic, sparse terms and summation orders are those of step2d_kernel (kernels_tiled2d.hip).
 #include "mifwi_internal.hpp"
 
+// The exchange below is written against the cache hierarchy of gfx942 / gfx950 and nothing else: a per-CU L1
+// that writes through, one L2 per XCD that serves every CU of that XCD, device-scope (sc1) loads that miss
+// the L1.  On any other target the counter store with group scope promises nothing to another CU.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__) && !defined(__gfx942__)
+#error "kernels_persist2d.hip relies on the L1 / per-XCD L2 behaviour of gfx942 and gfx950"
+#endif
+
 namespace mifwi {
 
 typedef int vi4 __attribute__((ext_vector_type(4)));
@@ -96,6 +103,7 @@ __global__ __launch_bounds__(256, 4) void persist2d_kernel(Persist2DArgs q)
     const int group_slot = s_misc[0], tile = s_misc[1];
     const int ntiles = a.ntx * a.ntz;
     if (group_slot >= a.nshots || tile >= ntiles) return;   // block-uniform: nothing to do on this XCD / surplus block
+    if (group_slot == q.drop_slot) return;                  // tests: an XCD that takes no part (its shot stays undone)
     const int shot = a.shot0 + group_slot;
 
     const int tile_x = tile / a.ntz, tile_z = tile - tile_x * a.ntz;
@@ -416,6 +424,58 @@ __global__ __launch_bounds__(256, 4) void persist2d_kernel(Persist2DArgs q)
                 if (ip) ip[i] = il[i];
             }
     }
+}
+
+// After a whole-loop launch: every tile of every shot of the group must have counted all its steps.  A shot whose
+// XCD received no block (a device with fewer than 8 XCDs, a partition mode) has waited for nobody and raised
+// nothing; this is what notices it.  One block.
+__global__ void persist2d_check_kernel(const int *done, int ncounters, int nsteps, int *abort_flag)
+{
+    int bad = 0;
+    for (int i = threadIdx.x; i < ncounters; i += blockDim.x) bad |= (done[i] != nsteps);
+    if (bad) *abort_flag = 1;
+}
+
+int launch_persist2d_check(const int *done, int ncounters, int nsteps, int *abort_flag, hipStream_t stream)
+{
+    hipLaunchKernelGGL(persist2d_check_kernel, dim3(1), dim3(256), 0, stream, done, ncounters, nsteps, abort_flag);
+    MIFWI_HIP(hipGetLastError());
+    return MIFWI_OK;
+}
+
+// Which XCC ids do the blocks of a launch land on?  One bit per id seen.
+__global__ void xcc_census_kernel(unsigned *mask)
+{
+    if (threadIdx.x == 0) {
+        const int xcc = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 15;
+        atomicOr(mask, 1u << xcc);
+    }
+}
+
+// Number of XCDs that blocks of a launch on the current device are dealt to when exactly the ids 0 .. n-1 are
+// seen, else 0.  The whole-loop kernel deals one shot to each of 8 ids; a device that shows another set (a
+// partition of the GPU, a part with fewer dies) must not run it.
+int persist2d_xcd_count(hipStream_t stream)
+{
+    unsigned *d = nullptr, h = 0;
+    if (hipMalloc((void **)&d, sizeof(unsigned)) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    bool ok = hipMemsetAsync(d, 0, sizeof(unsigned), stream) == hipSuccess;
+    if (ok) {
+        hipLaunchKernelGGL(xcc_census_kernel, dim3(512), dim3(64), 0, stream, d);
+        ok = hipGetLastError() == hipSuccess && hipMemcpyAsync(&h, d, sizeof(unsigned), hipMemcpyDeviceToHost, stream) == hipSuccess &&
+             hipStreamSynchronize(stream) == hipSuccess;
+    }
+    (void)hipFree(d);
+    if (!ok) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    int n = 0;
+    while (n < 16 && (h >> n & 1u)) ++n;
+    return (h >> n) == 0 ? n : 0;
 }
 
 template <int R, int TX, int TZ>

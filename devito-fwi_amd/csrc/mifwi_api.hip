@@ -219,6 +219,17 @@ static bool is_device_ptr(const void *ptr)
     return a.type == hipMemoryTypeDevice;
 }
 
+// device ordinal that owns a device pointer, -1 for anything else
+static int device_of_ptr(const void *ptr)
+{
+    hipPointerAttribute_t a{};
+    if (hipPointerGetAttributes(&a, ptr) != hipSuccess) {
+        (void)hipGetLastError();
+        return -1;
+    }
+    return a.type == hipMemoryTypeDevice ? a.device : -1;
+}
+
 // ---- the entry point that allocates nothing ------------------------------------------------------
 // Partial sums of mifwi_l2_misfit_noalloc live in this array instead of in memory from hipMalloc.  Every GPU
 // the library runs on holds its own copy, at its own address, until the process ends (128 KiB each).  In host
@@ -532,6 +543,7 @@ static int create(const mifwi_config *cfg, mifwi_plan **out)
         if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) p->ncu = prop.multiProcessorCount;
         if (const char *env = getenv("MIFWI_PERSIST")) p->persist = atoi(env);   // 0: one kernel per step always
         if (const char *env = getenv("MIFWI_PERSIST_SPIN")) p->persist_spin = atoi(env);   // tests: 0 abandons at once
+        if (const char *env = getenv("MIFWI_PERSIST_NOCHECK")) p->persist_check = atoi(env) == 0;   // tests only
     }
     if (cfg->ndim == 3 && cfg->dtype == MIFWI_F32 && !(cfg->flags & MIFWI_FLAG_GENERIC) && !ot4_untiled) {
         // 2.5-D fast path: 16 x 64 tiles of the (y, z) plane, x split into chunks so that one launch
@@ -561,6 +573,16 @@ static int create(const mifwi_config *cfg, mifwi_plan **out)
     if (hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking) != hipSuccess)
         return bail(fail(MIFWI_EHIP, "hipStreamCreate failed"));
     p->own_stream = true;
+    if (p->kind == 1 && p->persist) {
+        // the whole-loop kernel deals one shot to each of 8 XCDs: ask the device, once, where its blocks land
+        static std::mutex census_mutex;
+        static std::map<int, int> census;
+        std::lock_guard<std::mutex> lock(census_mutex);
+        auto it = census.find(dev);
+        if (it == census.end()) it = census.emplace(dev, persist2d_xcd_count(p->stream)).first;
+        p->xcds = it->second;
+        if (const char *env = getenv("MIFWI_FAKE_XCDS")) p->xcds = atoi(env);   // tests: pretend another device
+    }
     for (auto &pair : p->ev)
         for (hipEvent_t &e : pair)
             if (hipEventCreate(&e) != hipSuccess) return bail(fail(MIFWI_EHIP, "hipEventCreate failed"));
@@ -680,6 +702,7 @@ static void fill_stats(Plan &p, double ms, double steps, int nshots, double byte
     p.stats.algorithmic_bytes = p.stats.points * bytes_per_point * (p.esize / 4.0);
     p.stats.launches = launches;
     p.stats.kernel_kind = p.loop_persist ? 3 : p.kind;
+    (backward ? p.stats.bwd_kernel_kind : p.stats.fwd_kernel_kind) = p.stats.kernel_kind;
     p.loop_persist = false;
     p.stats.device_bytes = p.device_bytes;
     p.stats.ckpt_steps = p.ck_K > 0 ? p.ck_nc : 0;
@@ -1271,6 +1294,8 @@ static bool persist_eligible(Plan &p, int nshots, const SparseSet *sampled, bool
     if (p.cfg.flags & (MIFWI_FLAG_ASYNC | MIFWI_FLAG_NO_GRAPH)) return false;
     if (!((p.tile_tx == 32 && p.tile_tz == 32) || (p.tile_tx == 16 && p.tile_tz == 64)) || p.vec2d != 4) return false;
     if (p.cfg.nt < 3) return false;
+    // one shot per XCD, ids 0 .. 7, each with an equal share of the CUs: the full GPU in its single-partition mode
+    if (p.xcds != 8 || p.ncu % 8 != 0) return false;
     if ((unsigned long long)p.L.field * 12ull >= (1ull << 31)) return false;   // a shot's three levels behind one descriptor
     if (sampled && sampled->max_own > 256) return false;
     int &bpc = p.persist_bpc[grad ? 1 : 0];
@@ -1325,6 +1350,8 @@ static int enqueue_persist(Plan &p, int nshots, bool forward, bool with_grad, bo
     q.counter = p.d_psync + 8 * ntiles;
     q.abort_flag = q.counter + 16;
     q.spin_limit = p.persist_spin;
+    q.drop_slot = -1;
+    if (const char *env = getenv("MIFWI_PERSIST_DROP_SLOT")) q.drop_slot = atoi(env);   // tests
     const int resident = p.persist_bpc[with_grad ? 1 : 0] * (p.ncu / 8);
     launches = 0;
     for (int s0 = 0; s0 < nshots; s0 += 8) {
@@ -1332,6 +1359,8 @@ static int enqueue_persist(Plan &p, int nshots, bool forward, bool with_grad, bo
         q.a.shot0 = s0;
         q.a.nshots = std::min(8, nshots - s0);
         if ((rc = launch_persist2d(p, q, with_grad, std::min(resident, ntiles + 16), p.stream))) return rc;
+        // completion is explicit: a shot whose tiles did not all count nsteps steps makes the loop run anew
+        if (p.persist_check && (rc = launch_persist2d_check(q.done, q.a.nshots * ntiles, q.nsteps, q.abort_flag, p.stream))) return rc;
         launches += 1;
     }
     MIFWI_HIP(hipMemcpyAsync(p.h_abort, q.abort_flag, sizeof(int), hipMemcpyDeviceToHost, p.stream));
@@ -1466,6 +1495,7 @@ static int run_forward(Plan &p, int nshots, int save)
         if (*p.h_abort) {   // a block waited too long for a neighbour: this loop anew, and the next ones, a kernel per step
             p.persist_skip = p.persist_backoff;
             p.persist_backoff = std::min(4096, 2 * p.persist_backoff);
+            p.stats.persist_fallbacks += 1;
             return run_forward<T>(p, nshots, save);
         }
         p.loop_persist = true;
@@ -1600,6 +1630,7 @@ static int run_backward(Plan &p, int nshots, bool with_grad, bool with_illum)
         if (*p.h_abort) {
             p.persist_skip = p.persist_backoff;
             p.persist_backoff = std::min(4096, 2 * p.persist_backoff);
+            p.stats.persist_fallbacks += 1;
             return run_backward<T>(p, nshots, with_grad, with_illum);
         }
         p.loop_persist = true;
@@ -2527,8 +2558,16 @@ int mifwi_l2_misfit_noalloc(int32_t dtype, int32_t nshots, int64_t n_per_shot, c
                                       " shots per call (fixed scratch array)");
     if (n_per_shot < 0) return fail(MIFWI_EINVAL, "n_per_shot is negative");
     if (!syn || !obs || !residual_out || !fval) return fail(MIFWI_EINVAL, "null array argument");
-    for (const void *ptr : {syn, obs, (const void *)residual_out, (const void *)fval})
-        if (!is_device_ptr(ptr)) return fail(MIFWI_EINVAL, "mifwi_l2_misfit_noalloc takes device pointers only");
+    // the scratch array used is the current device's copy: the arrays (and the stream) must be that device's too
+    int cur = -1;
+    MIFWI_HIP(hipGetDevice(&cur));
+    for (const void *ptr : {syn, obs, (const void *)residual_out, (const void *)fval}) {
+        const int d = device_of_ptr(ptr);
+        if (d < 0) return fail(MIFWI_EINVAL, "mifwi_l2_misfit_noalloc takes device pointers only");
+        if (d != cur)
+            return fail(MIFWI_EINVAL, "mifwi_l2_misfit_noalloc: an array lives on device " + std::to_string(d) +
+                                          " but the current device is " + std::to_string(cur));
+    }
     hipStream_t stream = reinterpret_cast<hipStream_t>(hip_stream);
     GUARDED(dtype == MIFWI_F64 ? l2_misfit_noalloc<double>(nshots, (long)n_per_shot, syn, obs, residual_out, fval, stream)
                                : l2_misfit_noalloc<float>(nshots, (long)n_per_shot, syn, obs, residual_out, fval, stream));

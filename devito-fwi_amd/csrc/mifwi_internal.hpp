@@ -187,6 +187,8 @@ struct Plan {
     int persist_backoff = 64;          // and how many the next abandoned launch will cost (doubles, up to 4096)
     int persist_spin = 1 << 21;        // polls of a neighbour's counter before a loop is abandoned (MIFWI_PERSIST_SPIN)
     int persist_bpc[2] = {-1, -1};     // resident blocks per CU of the plain / gradient variant, -1 = not asked yet
+    bool persist_check = true;         // a one-block kernel behind every whole-loop launch verifies the tiles' step counts
+    int xcds = 0;                      // XCDs blocks are dealt to on this device (census at plan creation); the whole-loop kernel needs 8
     int *d_psync = nullptr;            // per-tile step counters [8][tiles], blocks taken per XCD [16], abort flag
     int *h_abort = nullptr;            // pinned host copy of the abort flag
     bool loop_persist = false;         // the loop whose statistics are being filled in ran that way
@@ -450,9 +452,14 @@ struct Persist2DArgs {
     int *counter;          // [16] blocks that have taken a tile, per XCD
     int *abort_flag;
     int spin_limit;        // polls of a neighbour's counter before the loop is abandoned
+    int drop_slot;         // -1; tests: blocks that land on this XCD leave at once, as if the device lacked it
 };
 int persist2d_blocks_per_cu(int R, int tile_tz, bool grad);
 int launch_persist2d(const Plan &p, const Persist2DArgs &q, bool grad, int blocks_per_xcd, hipStream_t stream);
+// sets *abort_flag unless done[0 .. ncounters) all equal nsteps (enqueued behind a whole-loop launch)
+int launch_persist2d_check(const int *done, int ncounters, int nsteps, int *abort_flag, hipStream_t stream);
+// XCDs the current device deals blocks to (ids 0 .. n-1 seen by a census launch), 0 when the ids have gaps
+int persist2d_xcd_count(hipStream_t stream);
 
 // ---- 2.5-D fast path for 3-D grids (kernels_3d.hip) -------------------------------------------
 struct Step3DArgs {

@@ -41,7 +41,9 @@ class _Stats(ctypes.Structure):
                 ("algorithmic_bytes", ctypes.c_double), ("fwd_ms", ctypes.c_double), ("bwd_ms", ctypes.c_double),
                 ("launches", ctypes.c_int32), ("fwd_launches", ctypes.c_int32), ("bwd_launches", ctypes.c_int32),
                 ("kernel_kind", ctypes.c_int32), ("device_bytes", ctypes.c_int64), ("ckpt_steps", ctypes.c_int32),
-                ("ckpt_segment", ctypes.c_int32)]
+                ("ckpt_segment", ctypes.c_int32), ("fwd_kernel_kind", ctypes.c_int32),
+                ("bwd_kernel_kind", ctypes.c_int32), ("persist_fallbacks", ctypes.c_int32),
+                ("reserved_", ctypes.c_int32)]
 
 KERNEL_NAMES = {0: ("step_generic_kernel", "step_generic_kernel<GRAD>"),
                 1: ("step2d_kernel", "step2d_kernel<GRAD>"),
@@ -387,5 +389,8 @@ class Plan(object):
         st = _Stats()
         self._check(self._lib.mifwi_get_stats(self._h, ctypes.byref(st)))
         out = {k: getattr(st, k) for k, _ in _Stats._fields_}
-        out["fwd_kernel"], out["bwd_kernel"] = KERNEL_NAMES.get(st.kernel_kind, ("?", "?"))
+        # names of the kernels the last forward and the last backward loop of the plan really ran on
+        out["fwd_kernel"] = KERNEL_NAMES.get(st.fwd_kernel_kind, ("?", "?"))[0]
+        out["bwd_kernel"] = KERNEL_NAMES.get(st.bwd_kernel_kind, ("?", "?"))[1]
+        out.pop("reserved_", None)
         return out

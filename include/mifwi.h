@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define MIFWI_VERSION 100
+#define MIFWI_VERSION 101
 
 enum {
     MIFWI_OK = 0,
@@ -144,6 +144,13 @@ typedef struct mifwi_stats {
     int32_t ckpt_steps;     /* leading time steps whose wavefield is kept as checkpoints and propagated a second
                                time by the gradient (0: every level is stored)                 */
     int32_t ckpt_segment;   /* steps per checkpoint segment (0: no checkpointing)             */
+    int32_t fwd_kernel_kind; /* kernel_kind of the last forward time loop                      */
+    int32_t bwd_kernel_kind; /* kernel_kind of the last backward time loop                     */
+    int32_t persist_fallbacks; /* time loops of this plan, since its creation, that were started as one launch
+                               (kernel_kind 3), did not complete -- a wait ran out, or a tile had not counted all
+                               its steps at the end -- and were run again with a kernel per step; 0 means every
+                               loop reported as kind 3 really ran that way                         */
+    int32_t reserved_;
 } mifwi_stats;
 
 MIFWI_API int mifwi_version(void);
@@ -230,7 +237,11 @@ MIFWI_API int mifwi_l2_misfit(mifwi_plan *plan, int32_t nshots, const void *syn,
  * `hip_stream` (NULL = the default stream) and the call returns without waiting.  It calls no hipMalloc / hipFree:
  * the partial sums live in a fixed array inside the library (128 KiB per GPU, held until the process ends), which
  * limits a call to 256 shots (MIFWI_EINVAL beyond).  All calls on one GPU share that array: calls that overlap in
- * time on one GPU (different streams) race; serialise them. */
+ * time on one GPU (different streams) race; serialise them.  The array used is the CURRENT device's: every array
+ * (and the stream) must belong to the current device, MIFWI_EINVAL otherwise.  The first call on a device looks the
+ * array's address up (hipGetSymbolAddress, which may load the code object): that must happen outside stream capture,
+ * so before the first captured call on a device make one eager call there, or create any plan on it
+ * (mifwi_plan_create does the same look-up). */
 MIFWI_API int mifwi_l2_misfit_noalloc(int32_t dtype, int32_t nshots, int64_t n_per_shot, const void *syn,
                             const void *obs, void *residual_out, double *fval, void *hip_stream);
 
@@ -241,8 +252,9 @@ MIFWI_API int mifwi_l2_misfit_noalloc(int32_t dtype, int32_t nshots, int64_t n_p
  * damp); phi may be NULL (2-D, or no azimuth).  space_order must be divisible by 4; 2-D or 3-D.
  * mifwi_tti_forward replaces op_fwd('centered').apply (wavesolver.py:160-166): the wavelet drives
  * both fields, rec_out (nshots, nt, nrec) samples u + v; save != 0 keeps every level of u and v on the
- * device (TimeFunction(save=nt), wavesolver.py:127-137) for mifwi_tti_gradient -- 2 * nt fields per shot,
- * no checkpointing on this path.  mifwi_tti_adjoint replaces op_adj().apply (wavesolver.py:208-215):
+ * device (TimeFunction(save=nt), wavesolver.py:127-137) for mifwi_tti_gradient -- 2 * nt fields per shot, or,
+ * when those do not fit, pairs of levels every K steps from which the gradient call propagates one segment at a
+ * time again (same bits; mifwi_read_wavefield which = 7, 8 is refused then).  mifwi_tti_adjoint replaces op_adj().apply (wavesolver.py:208-215):
  * rec_in (nshots, nt, nrec) -> srca_out (nshots, nt, nsrc).  The last three levels of (u, v) and (p, r)
  * are readable through mifwi_read_wavefield which = 3, 4 and 5, 6, the saved levels of u and v through
  * which = 7 and 8. */

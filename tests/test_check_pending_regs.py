@@ -61,3 +61,17 @@ def test_touching_a_register_in_flight_is_found(tmp_path):
 def test_copy_across_the_loop_edge_is_found(tmp_path):
     bad, nfun = _run(tmp_path, BAD_ACROSS_EDGE, "demo_kernel_edge")
     assert nfun == 1 and bad >= 1
+
+
+# spill traffic (scratch_*) counts against the same counter as the hand-issued loads and is walked as an entry: here
+# the reloaded register is read while the reload is still in flight (vmcnt(1) retires the two global loads only)
+SPILL_IN_FLIGHT = GOOD.replace("demo_kernel_good", "demo_kernel_spill").replace(
+    "\tv_add_f32_e32 v9, v9, v9\n", "\tscratch_load_dword v11, off, s32 offset:4\n").replace(
+    "\tv_add_f32_e32 v9, v0, v1\n", "\tv_add_f32_e32 v9, v0, v11\n")
+
+
+def test_spill_reload_is_walked_as_an_entry(tmp_path):
+    bad, nfun = _run(tmp_path, SPILL_IN_FLIGHT, "demo_kernel_spill")
+    assert nfun == 1 and bad >= 1
+    assert check_pending_regs.scratch_ops(str(tmp_path / "k.s"), ["demo_kernel_spill"]) == 1
+    assert check_pending_regs.scratch_ops(str(tmp_path / "k.s"), ["no_such_kernel"]) == 0

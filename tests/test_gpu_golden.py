@@ -44,6 +44,13 @@ def test_gpu_reproduces_golden(name):
     assert rel_l2(out["illum"][0][crop], g["illum"]) < 1e-4
     u_last = plan.read_wavefield(0, shot=0, first=nt - 1, count=1)
     assert np.isclose(np.linalg.norm(u_last.astype(np.float64)), float(g["u_last_norm"]), rtol=1e-5)
+    # the kernels that were checked are the ones the benchmark runs: 2-D loops as one launch each, none repeated
+    st = plan.stats()
+    assert st["persist_fallbacks"] == 0
+    if ndim == 2:
+        assert st["fwd_kernel"] == "persist2d_kernel" and st["bwd_kernel"] == "persist2d_kernel<GRAD>", st
+    else:
+        assert st["fwd_kernel"] == "step3d_kernel" and st["bwd_kernel"] == "step3d_kernel<GRAD>", st
     plan.close()
 
 
@@ -81,6 +88,8 @@ def test_marmousi2_golden_shot_inside_a_batch(batch, pos):
     crop = (slice(nbl, -nbl), slice(nbl, -nbl))
     assert rel_l2(out["grad"][pos][crop], g["grad"]) < 1e-4
     assert rel_l2(out["illum"][pos][crop], g["illum"]) < 1e-4
+    st = plan.stats()
+    assert st["fwd_kernel"] == "persist2d_kernel" and st["bwd_kernel"] == "persist2d_kernel<GRAD>" and st["persist_fallbacks"] == 0, st
     # a shot's numbers do not depend on its neighbours in the batch: the same shot alone gives the same bits
     single = mifwi.Plan(m_true.grid.shape, c["spacing"], m_true.grid.origin, so, nt, dt, 1, g["rec"].shape[0])
     single.set_geometry(src[pos:pos + 1], g["rec"])

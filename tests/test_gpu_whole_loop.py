@@ -33,8 +33,9 @@ def _run(plan, case, res):
     st_b = plan.stats()
     srca = plan.adjoint(res)
     rec2 = plan.forward(case.wavelet, save=False)
+    st_e = plan.stats()
     return dict(rec=rec, u=u, g=g, il=il, srca=srca, rec2=rec2, fwd_kernel=st_f["fwd_kernel"], bwd_kernel=st_b["bwd_kernel"],
-                launches=(st_f["fwd_launches"], st_b["bwd_launches"]))
+                launches=(st_f["fwd_launches"], st_b["bwd_launches"]), fallbacks=st_e["persist_fallbacks"])
 
 
 # shape, space order, shots, sources per shot: 32 x 32 and 16 x 64 tiles, ragged edges in both directions, rows whose
@@ -58,6 +59,7 @@ def test_whole_loop_launch_equals_kernel_per_step_and_oracle(mifwi, shape, so, n
     a, b = out["loop"], out["steps"]
     assert a["fwd_kernel"] == "persist2d_kernel" and a["bwd_kernel"] == "persist2d_kernel<GRAD>", a
     assert a["launches"] == ((nshots + 7) // 8, (nshots + 7) // 8)
+    assert a["fallbacks"] == 0 and b["fallbacks"] == 0
     assert b["fwd_kernel"] == "step2d_kernel" and b["launches"][0] == case.nt - 2
     assert np.array_equal(a["rec"], a["rec2"])          # saving changes nothing
     for key, tol in (("rec", 1e-5), ("u", 1e-5), ("srca", 1e-5), ("g", 5e-5), ("il", 1e-5)):
@@ -110,8 +112,40 @@ def test_abandoned_whole_loop_is_repeated_with_a_kernel_per_step(mifwi, monkeypa
     got = _run(plan, case, res)
     plan.close()
     assert got["fwd_kernel"] == "step2d_kernel" and got["bwd_kernel"] == "step2d_kernel<GRAD>"
+    assert got["fallbacks"] >= 1 and want["fallbacks"] == 0
     for key in ("rec", "u", "g", "il", "srca", "rec2"):
         assert np.array_equal(got[key], want[key]), key
+
+
+def test_a_shot_whose_xcd_takes_no_part_is_noticed(mifwi, monkeypatch):
+    """On a device that deals no block to one of the XCD ids (a partition of the GPU, a part with fewer dies) the
+    shot dealt to that id would stay untouched while nobody waits for it.  The step counts of every tile are
+    checked behind the launch: the loop is then run again with a kernel per step, and counted."""
+    case = Case((70, 50), (10., 10.), 10, 8, nt=80, nshots=3, nrec=7, seed=4, f0=0.03)
+    rng = np.random.default_rng(9)
+    res = rng.standard_normal((3, case.nt, case.nrec)).astype(np.float32)
+    ref = case.plan(mifwi, flags=mifwi.FLAG_NO_GRAPH)
+    want = _run(ref, case, res)
+    ref.close()
+    monkeypatch.setenv("MIFWI_PERSIST_DROP_SLOT", "1")
+    plan = case.plan(mifwi)
+    got = _run(plan, case, res)
+    plan.close()
+    assert got["fwd_kernel"] == "step2d_kernel" and got["fallbacks"] >= 1
+    for key in ("rec", "u", "g", "il", "srca", "rec2"):
+        assert np.array_equal(got[key], want[key]), key
+    assert np.abs(got["rec"][1]).max() > 0 and np.abs(got["g"][1]).max() > 0   # the dropped shot was modelled after all
+
+
+def test_devices_without_eight_xcds_keep_the_kernel_per_step(mifwi, monkeypatch):
+    case = Case((40, 40), (10., 10.), 10, 8, nt=40, nshots=2, nrec=5, seed=4, f0=0.03)
+    for fake in ("4", "1", "0"):
+        monkeypatch.setenv("MIFWI_FAKE_XCDS", fake)
+        plan = case.plan(mifwi)
+        plan.forward(case.wavelet)
+        st = plan.stats()
+        assert st["fwd_kernel"] == "step2d_kernel" and st["persist_fallbacks"] == 0, fake
+        plan.close()
 
 
 def test_switch_and_flags_that_keep_the_kernel_per_step(mifwi, monkeypatch):

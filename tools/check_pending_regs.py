@@ -1,7 +1,8 @@
 """Static check of the hand-scheduled kernels in an assembly listing (hipcc -S --cuda-device-only): between a
 global_load and the s_waitcnt that covers it, no instruction may read or write the load's destination registers.
 The function body is walked in layout order, its largest loop twice (for the registers that live across the loop
-edge); loads return in order, stores are counted as outstanding entries without registers.
+edge); loads return in order, stores are counted as outstanding entries without registers; scratch (spill) and flat
+accesses count against the same counter and are walked as entries too.
 usage: python tools/check_pending_regs.py file.s <mangled-name-fragment> [...]"""
 import re, sys
 
@@ -33,10 +34,13 @@ def check(lines, name):
             if p & used:
                 bad += 1
                 print("%s: '%s' touches registers of a load in flight %s" % (name, l, sorted(p & used)))
-        if op.startswith("global_load") or op.startswith("buffer_load"):
+        # everything that counts against vmcnt is an entry: spill traffic (scratch_*) and flat accesses too, or a
+        # reload the compiler places inside a hand-issued batch would make the batch's counted wait one entry short
+        if op.startswith(("global_load", "buffer_load", "scratch_load", "flat_load")):
             pend.append(regs(l.split(",")[0]))
             nload += 1
-        elif op.startswith("global_store") or op.startswith("buffer_store") or op.startswith("global_atomic"):
+        elif op.startswith(("global_store", "buffer_store", "scratch_store", "flat_store", "global_atomic", "buffer_atomic",
+                            "flat_atomic")):
             pend.append(set())
     print("%s: %d loads walked, %d violations" % (name, nload, bad))
     return bad
@@ -58,6 +62,17 @@ def check_file(path, frags):
             total += check(body, m.group(1))
             nfun += 1
     return total, nfun
+
+
+def scratch_ops(path, frags):
+    """Spill instructions (scratch_load / scratch_store) in the bodies of the functions `check_file` would walk."""
+    s = open(path).read()
+    n = 0
+    for frag in frags:
+        for m in re.finditer(r"^(\S*%s\S*):[^\n]*\n" % re.escape(frag), s, re.M):
+            body = s[m.end():s.index("s_endpgm", m.end())]
+            n += len(re.findall(r"^\s*scratch_(?:load|store)", body, re.M))
+    return n
 
 
 if __name__ == "__main__":
