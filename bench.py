@@ -20,7 +20,9 @@ Rank 0 prints ONE JSON line.  `roofline` describes the dominant kernel (the grad
 on the host cores for a bounded sample of the same workload, in two modes: shots one after the other
 with every core on one shot (how the reference runs), and one shot per core side by side.
 At N = 1 `shot_batches` times the same gradient evaluation for batches of 4 and 32 shots: their ratio is
-what eight GPUs with 4 shots each can gain over one GPU with all 32 (before the all-reduce).
+what eight GPUs with 4 shots each can gain over one GPU with all 32 (before the all-reduce).  At every N
+`strong_scaling` times a fixed 32-shot survey (BASELINE config 3) and a fixed 8-shot survey split evenly over the
+ranks, next to the weak-scaling headline (8 shots per GPU).
 """
 import argparse
 import json
@@ -420,6 +422,53 @@ def shot_batches(mifwi, torch, dev, local_rank, true_model, init_model, rec, so,
     return out
 
 
+def strong_scaling(mifwi, torch, dist, use_dist, dev, local_rank, rank, world, true_model, init_model, rec, so, flags,
+                   totals=(32, 8), reps=3):
+    """Fixed surveys sharded over the ranks (strong scaling), timed like the headline: barrier + synchronize on both
+    sides, maximum over ranks.  32 shots = BASELINE config 3 (32 / N per GPU), 8 shots = the survey of the BASELINE
+    metric's wording (8 / N per GPU).  Run at every N, so that the driver's runs at N = 1, 2, 4, 8 give the curve
+    time(N = 1) / time(N): the shot-parallel gradient speed-up."""
+    out = {}
+
+    def barrier():
+        torch.cuda.synchronize()
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for total in totals:
+        key = "%d_shot_survey" % total
+        if total % world:
+            out[key] = {"skipped": "%d shots do not divide over %d GPUs" % (total, world)}
+            continue
+        per = total // world
+        src_all, _ = acquisition(true_model, total)
+        sv = Survey(mifwi, torch, dev, local_rank, true_model, init_model, src_all[rank * per:(rank + 1) * per], rec, so,
+                    flags, dist if use_dist else None)
+        sv.step()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            _, st = sv.step()
+        barrier()
+        el = (time.perf_counter() - t0) / reps
+        if use_dist:
+            t = torch.tensor([el], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        steps = sv.nt - 2
+        out[key] = {"shots_total": total, "shots_per_gpu": per, "n_gpus": world, "gradient_eval_ms": el * 1e3,
+                    "gpoints_per_s": 2.0 * steps * sv.ngrid * total / el / 1e9,
+                    "forward_us_per_step": st["fwd_ms"] / steps * 1e3, "gradient_us_per_step": st["bwd_ms"] / steps * 1e3,
+                    "fwd_kernel": st["fwd_kernel"], "bwd_kernel": st["bwd_kernel"],
+                    "persist_fallbacks": st["persist_fallbacks"]}
+        sv.close()
+    out["what"] = ("gradient evaluation (forward with saved wavefield + gradient + muting + shot sum + all-reduce) of a "
+                   "FIXED survey split evenly over the GPUs; speed-up at N GPUs = gradient_eval_ms at n_gpus 1 / "
+                   "gradient_eval_ms at n_gpus N")
+    return out
+
+
 def main():
     # The result line is the only thing this program writes to its standard output: libraries that print banners
     # there (RCCL prints its version when a communicator is created) are pointed at standard error instead.
@@ -438,6 +487,7 @@ def main():
     ap.add_argument("--no-3d", action="store_true", help="skip the 3-D measurements (stencil roofline, 512^3 gradient)")
     ap.add_argument("--no-tti", action="store_true", help="skip the 2-D TTI measurement")
     ap.add_argument("--no-batches", action="store_true", help="skip the 4- and 32-shot batch timings")
+    ap.add_argument("--no-strong", action="store_true", help="skip the strong-scaling legs (32- and 8-shot surveys sharded over the GPUs)")
     ap.add_argument("--flags", type=int, default=0, help="MIFWI_FLAG_* bits for the plan (debugging)")
     args = ap.parse_args()
 
@@ -516,6 +566,10 @@ def main():
     barrier()
     fwd_only_ms = (time.perf_counter() - t0) / args.steps * 1e3
 
+    if st["persist_fallbacks"] != 0:
+        # a whole-loop launch that was abandoned and run again a kernel per step would make the line describe a
+        # mixture of two schedules
+        print("warning: %d whole-loop launches were repeated with a kernel per step" % st["persist_fallbacks"], file=sys.stderr)
     pts_per_step = 2.0 * (nt - 2) * ngrid * per_gpu * world
     value = pts_per_step * args.steps / elapsed / 1e9
     fval = float(packed[-1].item())
@@ -608,6 +662,8 @@ def main():
                    "parallelism": "shots sharded %d per GPU" % per_gpu},
         "gradient_eval_ms": elapsed / args.steps * 1e3,
         "forward_only_eval_ms": fwd_only_ms,
+        "kernels": {"forward_loop": st["fwd_kernel"], "backward_loop": st["bwd_kernel"],
+                    "whole_loop_launches_repeated_kernel_per_step": st["persist_fallbacks"]},
         "objective": fval,
         "roofline": roofline, "roofline_forward": roofline_fwd,
     }
@@ -622,6 +678,10 @@ def main():
                             "expected_from_parts_ms": out["gradient_eval_ms"] + it_k * fwd_only_ms,
                             "what": "fwi.fwi_loss through the Python API: model update, batched shots, "
                                     "muting, preconditioner, mask, all-reduce"}
+    if not args.no_strong:
+        # every rank takes part (the surveys are sharded over the ranks); rank 0 keeps the result
+        out["strong_scaling"] = strong_scaling(mifwi, torch, dist, use_dist, dev, local_rank, rank, world, true_model,
+                                               init_model, rec, so, args.flags)
     if rank == 0 and world == 1 and not args.no_batches and not strong:
         out["shot_batches"] = shot_batches(mifwi, torch, dev, local_rank, true_model, init_model, rec, so, args.flags)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

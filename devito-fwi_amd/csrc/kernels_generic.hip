@@ -33,6 +33,30 @@ __device__ inline T star(const StepConsts<T> &k, const T *f)
     return lap;
 }
 
+// The same at a point of row i2 (last dimension) below a free surface (operators.py:8-35): in the rows
+// z < space_order a term f[z-j] with a negative offset becomes sign(z-j) * f[|z-j|].
+template <typename T, int R, int ND>
+__device__ inline T star_fs(const StepConsts<T> &k, const T *f, int i2)
+{
+    if (i2 >= 2 * R) return star<T, R, ND>(k, f);
+    T lap = k.c0 * f[0];
+#pragma unroll
+    for (int j = 1; j <= R; ++j) {
+        const int zz = i2 - j;
+        const T lo = zz > 0 ? f[-j] : (zz < 0 ? -f[-i2 - zz] : T(0));
+        lap += k.c[2][j] * (lo + f[j]);
+    }
+    if (ND >= 2) {
+#pragma unroll
+        for (int j = 1; j <= R; ++j) lap += k.c[1][j] * (f[-j * k.s1] + f[j * k.s1]);
+    }
+    if (ND >= 3) {
+#pragma unroll
+        for (int j = 1; j <= R; ++j) lap += k.c[0][j] * (f[-j * k.s0] + f[j * k.s0]);
+    }
+    return lap;
+}
+
 template <typename T, int R, int ND>
 __global__ __launch_bounds__(256) void lap_scale_kernel(StepConsts<T> k, const T *in, long in_shot_stride,
                                                         const T *m, int power, T *out, long out_shot_stride)
@@ -43,7 +67,11 @@ __global__ __launch_bounds__(256) void lap_scale_kernel(StepConsts<T> k, const T
     const int i0 = blockIdx.z - shot * k.n0;
     if (i2 >= k.n2 || i1 >= k.n1) return;
     const long p = k.off0 + (long)i0 * k.s0 + (long)i1 * k.s1 + i2;
-    const T lap = star<T, R, ND>(k, in + (long)shot * in_shot_stride + p);
+    // power 1 is the inner half of the OT4 stencil term, which the free-surface rewrite of the update reaches into
+    // (every field read through a negative offset is mirrored); power 2 belongs to the gradient's correlation term,
+    // which the reference leaves as it is (operators.py:219 is not passed through freesurface())
+    const T *f = in + (long)shot * in_shot_stride + p;
+    const T lap = (k.fs && power == 1) ? star_fs<T, R, ND>(k, f, i2) : star<T, R, ND>(k, f);
     const T mz = m[p];
     out[(long)shot * out_shot_stride + p] = power == 1 ? lap / mz : lap / (mz * mz);
 }
@@ -81,7 +109,12 @@ __global__ __launch_bounds__(256) void step_generic_kernel(StepConsts<T> k, Step
 #pragma unroll
         for (int j = 1; j <= R; ++j) lap += k.c[0][j] * (cur[-j * k.s0] + cur[j * k.s0]);
     }
-    if (sp.ot4) lap += k.dt2 / T(12) * star<T, R, ND>(k, sp.ot4 + (long)shot * k.field + p);
+    if (sp.ot4) {
+        // laplace(u)/m read through a negative offset is mirrored like u itself: 1/m = vp^2 keeps its sign (the two
+        // signs of vp cancel) and the inner Laplacian of the antisymmetric field changes it
+        const T *w = sp.ot4 + (long)shot * k.field + p;
+        lap += k.dt2 / T(12) * (k.fs ? star_fs<T, R, ND>(k, w, i2) : star<T, R, ND>(k, w));
+    }
     const T mz = sp.m[p];
     const T ed = sp.eta[p] * k.dt;
     const T uo = sp.old[(long)shot * sp.shot_stride + p];

@@ -485,8 +485,6 @@ static int validate(const mifwi_config &c)
     if (c.dtype != MIFWI_F32 && c.dtype != MIFWI_F64) return fail(MIFWI_EINVAL, "dtype must be MIFWI_F32 or MIFWI_F64");
     if (c.nsrc < 0 || c.nrec < 0) return fail(MIFWI_EINVAL, "nsrc/nrec must be non-negative");
     if (c.max_shots < 1) return fail(MIFWI_EINVAL, "max_shots must be at least 1");
-    if ((c.flags & MIFWI_FLAG_OT4) && (c.flags & MIFWI_FLAG_FREE_SURFACE))
-        return fail(MIFWI_EINVAL, "the OT4 kernel is not available with a free surface");
     if (c.flags & MIFWI_FLAG_PML) {
         if (c.ndim != 2) return fail(MIFWI_EINVAL, "the perfectly matched layer is available for 2-D grids only");
         if (c.flags & (MIFWI_FLAG_OT4 | MIFWI_FLAG_FREE_SURFACE))
@@ -528,7 +526,8 @@ static int create(const mifwi_config *cfg, mifwi_plan **out)
     if (const char *env = getenv("MIFWI_2D_VEC")) p->vec2d = atoi(env);  // tuning experiments
     // the fourth-order-in-time kernel runs on the tiled kernels too (see Step2DArgs::pt), except with
     // half-precision saved levels (its gradient stencils the saved level)
-    const bool ot4_untiled = (cfg->flags & MIFWI_FLAG_OT4) && ((cfg->flags & MIFWI_FLAG_SAVE_F16) || getenv("MIFWI_OT4_UNTILED"));
+    // ... and with a free surface (the mirrored reads reach into laplace(u)/m as well: untiled kernels only)
+    const bool ot4_untiled = (cfg->flags & MIFWI_FLAG_OT4) && ((cfg->flags & (MIFWI_FLAG_SAVE_F16 | MIFWI_FLAG_FREE_SURFACE)) || getenv("MIFWI_OT4_UNTILED"));
     if (cfg->ndim == 2 && cfg->dtype == MIFWI_F32 && !(cfg->flags & (MIFWI_FLAG_GENERIC | MIFWI_FLAG_PML)) && !ot4_untiled) {
         // tiled fast path: pick the tile shape that wastes fewer threads on this grid
         const int n1 = p->L.n[1], n2 = p->L.n[2];

@@ -2,8 +2,9 @@
 `AcousticWaveSolver` with the call signatures of the reference's
 seismic/acoustic/wavesolver.py:10-246, executing on an MI355X through libmifwi instead of
 through Devito-generated C.  forward / adjoint / jacobian (alias born) / jacobian_adjoint (alias
-gradient) are implemented for the OT2 and OT4 kernels; OT2 also with a free surface.  The
-pyrevolve `checkpointing=True` keyword is not part of this package and raises.
+gradient) are implemented for the OT2 and OT4 kernels, both also with a free surface.
+`jacobian_adjoint(checkpointing=True)` models the forward wavefield again from `geometry.src`, as the
+reference's pyrevolve branch does, with the library's own device checkpointing.
 """
 import numpy as np
 
@@ -57,8 +58,6 @@ class AcousticWaveSolver(object):
         assert self.model.grid == geometry.grid
         if kernel not in ('OT2', 'OT4'):
             raise ValueError("Unrecognized kernel")
-        if kernel == 'OT4' and getattr(model, 'fs', False):
-            raise NotImplementedError("the OT4 kernel is not available with a free surface")
         self.space_order = space_order
         self.kernel = kernel
         self._device = kwargs.pop('device', -1)
@@ -72,12 +71,12 @@ class AcousticWaveSolver(object):
         return self.model.critical_dt
 
     # -- plumbing -----------------------------------------------------------------------------
-    def _entry(self, dt, nsrc, nrec, nt):
+    def _entry(self, dt, nsrc, nrec, nt, extra_flags=0):
         from mifwi import engine
         m = self.model
         from mifwi import FLAG_FREE_SURFACE, FLAG_OT4, FLAG_PML
         flags = (FLAG_FREE_SURFACE if getattr(m, 'fs', False) else 0) | (FLAG_OT4 if self.kernel == 'OT4' else 0)
-        flags |= FLAG_PML if self._pml else 0
+        flags |= (FLAG_PML if self._pml else 0) | extra_flags
         return engine.get_plan(m.grid.shape, m.spacing, m.grid.origin, self.space_order, nt, dt, nsrc, nrec,
                                max_shots=1, dtype=m.dtype, device=self._device, flags=flags)
 
@@ -150,14 +149,25 @@ class AcousticWaveSolver(object):
         (wavesolver.py:153-205).  Extension: a Function passed as `illum` also receives (is incremented
         by) the sum over time of u^2, which the gradient kernel forms from the saved wavefield anyway."""
         self._no_pml()
-        if checkpointing:
-            raise NotImplementedError("pyrevolve checkpointing is not available; the saved wavefield stays on the GPU")
         dt = kwargs.pop('dt', self.dt)
         grad = grad or Function(name='grad', grid=self.model.grid)
         nt = rec.data.shape[0]
-        entry = self._entry(dt, self.geometry.nsrc, rec.data.shape[1], nt)
-        self._load(entry, vp, self.geometry.src_positions, rec.coordinates.data)
-        if not (isinstance(u, DeviceTimeFunction) and u._entry is entry and u.on_device()):
+        if checkpointing:
+            # wavesolver.py:188-201: `u` is not used; the forward wavefield is modelled again from geometry.src and
+            # kept as checkpoints from which the backward pass propagates one segment at a time again (here the
+            # library's device checkpointing, MIFWI_FLAG_CHECKPOINT, in place of pyrevolve)
+            from mifwi import FLAG_CHECKPOINT
+            src = self.geometry.src
+            entry = self._entry(dt, src.data.shape[1], rec.data.shape[1], nt, extra_flags=FLAG_CHECKPOINT)
+            self._load(entry, vp, src.coordinates.data, rec.coordinates.data)
+            entry.claim(0), entry.claim(1)
+            entry.plan.forward(src.data, nshots=1, save=True, want_rec=False)
+        else:
+            entry = self._entry(dt, self.geometry.nsrc, rec.data.shape[1], nt)
+            self._load(entry, vp, self.geometry.src_positions, rec.coordinates.data)
+        if checkpointing:
+            pass
+        elif not (isinstance(u, DeviceTimeFunction) and u._entry is entry and u.on_device()):
             ud = np.ascontiguousarray(u.data, dtype=self.model.dtype)
             assert ud.shape[0] == nt, "u must hold every time level (created with save=True)"
             entry.claim(0)

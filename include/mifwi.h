@@ -73,7 +73,8 @@ enum {
                                     38-56,216-219).  Float32 plans run it on the tiled kernels: the Laplacian is
                                     linear, so a launch writes z = u + dt^2/12 laplace(u)/m and the step proper
                                     stencils z (with MIFWI_FLAG_SAVE_F16, and in float64, on the untiled
-                                    kernels).  Not combinable with MIFWI_FLAG_FREE_SURFACE.  The caller passes
+                                    kernels; with MIFWI_FLAG_FREE_SURFACE on the untiled kernels too: the
+                                    mirrored reads of operators.py:8-35 then apply to laplace(u)/m as well).  The caller passes
                                     dt = 1.73 * CFL dt as the reference's solver does (wavesolver.py:41-46). */
     MIFWI_FLAG_TIME_BLOCK = 128, /* 3-D float32 forward modelling without saving: two time steps per sweep over the
                                     grid.  x is cut into slabs; the second step follows the first one slab behind, so

@@ -156,7 +156,6 @@ class Problem(object):
         self.fs = bool(fs)
         assert kernel in ('OT2', 'OT4')
         self.ot4 = int(kernel == 'OT4')
-        assert not (self.ot4 and self.fs), 'OT4 with a free surface is not restated'
         origin_pad = [float(self.dtype.type(o - s * self.nbl)) for o, s in zip(self.origin, self.spacing)]
         shape_pad = [s + 2 * self.nbl for s in self.shape]
         if self.fs:                                   # model.py:106-110

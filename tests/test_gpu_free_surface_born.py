@@ -234,6 +234,47 @@ def test_ot4_stability_and_solver_dt():
         assert np.isfinite(np.linalg.norm(rec.data))
 
 
-def test_ot4_free_surface_rejected(mifwi):
-    with pytest.raises(mifwi.MifwiError):
-        mifwi.Plan((20, 20), (10.0, 10.0), (0.0, 0.0), 4, 10, 1.0, 1, 1, flags=16 | 32)
+# OT4 with a free surface (operators.py:8-35 applied to the OT4 update of operators.py:52-56): the reference's
+# freesurface() mirrors every function read through a negative z offset, the factors of the biharmonic included.
+# No number of the reference pins it (parity unpinned); the library runs it on the untiled kernels in both
+# precisions and is checked against the restatement, sources and receivers in the first cells below the surface.
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("so", [4, 8])
+def test_2d_ot4_free_surface(mifwi, so, dtype):
+    case = _shallow(Case((47, 40), (10.0, 10.0), nbl=9, space_order=so, nt=130, nshots=2, nrec=13, fs=True,
+                         kernel='OT4', dtype=dtype, seed=21))
+    _check_case(mifwi, case)
+    plan = case.plan(mifwi)
+    plan.forward(case.wavelet)
+    assert plan.stats()["fwd_kernel"] == "step_generic_kernel"
+    plan.close()
+
+
+def test_3d_ot4_free_surface(mifwi):
+    case = _shallow(Case((20, 23, 30), (10.0, 10.0, 10.0), nbl=5, space_order=4, nt=40, nshots=1, nrec=9,
+                         fs=True, kernel='OT4', seed=22))
+    _check_case(mifwi, case)
+
+
+def test_ot4_free_surface_differs_from_absorbing_top(mifwi):
+    kw = dict(nbl=9, space_order=8, nshots=1, nrec=13, seed=23)
+    both = _shallow(Case((47, 40), (10.0, 10.0), nt=130, fs=True, kernel='OT4', **kw))
+    ab = Case((47, 40), (10.0, 10.0), nt=130, fs=False, kernel='OT4', **kw)
+    ab.src[:], ab.rec[:] = both.src, both.rec
+    r_both = both.plan(mifwi).forward(both.wavelet)
+    r_ab = ab.plan(mifwi).forward(ab.wavelet)
+    assert rel_l2(r_both, r_ab) > 0.3
+
+
+def test_ot4_free_surface_through_the_solver():
+    """acoustic_example.py:26-63 run(fs=True, kernel='OT4'): the reference builds this operator; here it must run."""
+    from seismic import demo_model, setup_geometry
+    from seismic.acoustic import AcousticWaveSolver
+    model = demo_model('layers-isotropic', space_order=4, shape=(31, 33), nbl=8, dtype=np.float32, spacing=(15.0, 15.0),
+                       fs=True)
+    geometry = setup_geometry(model, 300.0)
+    solver = AcousticWaveSolver(model, geometry, kernel='OT4', space_order=4)
+    rec, u, _ = solver.forward(save=True)
+    assert np.isfinite(np.linalg.norm(rec.data)) and np.linalg.norm(rec.data) > 0
+    grad, _ = solver.jacobian_adjoint(rec, u)
+    assert np.isfinite(grad.data).all() and np.abs(grad.data).max() > 0

@@ -212,3 +212,28 @@ def test_wasserstein_device_route_matches_host_route(with_direct):
         total += f_
         assert rel_l2(out[True][2][i], r_) <= 1e-5
     assert abs(out[True][0] - total) <= 1e-7 * total
+
+
+@pytest.mark.parametrize("dtype,ndim", [(np.float32, 2), (np.float64, 2), (np.float32, 3)])
+def test_jacobian_adjoint_checkpointing_keyword(dtype, ndim):
+    """acoustic_example.py:26-63 run(full_run=True, checkpointing=True) and wavesolver.py:188-201: the forward
+    wavefield is not saved by the caller; jacobian_adjoint models it again from geometry.src and runs the backward
+    pass from checkpoints.  The gradient must equal the one from the fully saved wavefield (same arithmetic; the
+    two plans run different schedules in 2-D float32, hence the rounding-level tolerance)."""
+    from seismic import demo_model, setup_geometry
+    from seismic.acoustic import AcousticWaveSolver
+    from mifwi import engine
+    shape = (41, 37) if ndim == 2 else (21, 23, 25)
+    model = demo_model('layers-isotropic', space_order=8, shape=shape, nbl=10, dtype=dtype, spacing=(15.0,) * ndim)
+    geometry = setup_geometry(model, 400.0)
+    solver = AcousticWaveSolver(model, geometry, space_order=8)
+    rec, u, _ = solver.forward(save=True)
+    g_saved, _ = solver.jacobian_adjoint(rec, u)
+    saved = np.array(g_saved.data)
+    rec2, u2, _ = solver.forward(save=False)               # as run(checkpointing=True) does: nothing saved
+    assert np.array_equal(rec2.data, rec.data)
+    g_ck, summary = solver.jacobian_adjoint(rec2, u2, checkpointing=True)
+    assert summary["ckpt_steps"] > 0
+    assert np.abs(saved).max() > 0
+    assert rel_l2(g_ck.data, saved) < (1e-4 if dtype == np.float32 else 1e-11)
+    engine.clear()
