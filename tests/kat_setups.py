@@ -41,6 +41,26 @@ def circle_kat():
                 kat=dict(objective=39113.0, gmin=-821.0, gmax=2442.0, objective_it5=3828.0, atol=10.0))
 
 
+def circle_notebook_kat():
+    """
+    Inputs and printed output of seismic/tutorials/03_fwi.ipynb (cells 3-24): the set-up of circle_kat() with the
+    shots at 30 m instead of 20 m (cell 16) and five gradient-descent steps whose objective values cell 24 prints.
+
+    The printed values were recorded with a Devito release whose `critical_dt` was 0.42 * h / vp_max = 1.4 ms for
+    this model (the 2-D constant of that era) rather than today's 2.041 ms from the stencil weights
+    (seismic/model.py:338-370); the objective is a sum over time samples, so it scales with 1/dt.  With dt = 1.4
+    (nt = 716) the restatement gives 57284.98, 35766.02, 21002.24, 11547.93, 5785.97 against the printed
+    57285.10, 35766.90, 21002.93, 11548.23, 5786.19; with dt = 2.041 it gives 39293.  The time step is therefore
+    passed as `dt=`, which the reference's model honours (seismic/model.py:355-370).
+    """
+    c = circle_kat()
+    c["src_positions"][:, 0] = 30.0
+    c["dt"] = np.float32(1.4)
+    c["kat"] = dict(history=(57285.103209, 35766.902505, 21002.932951, 11548.234192, 5786.186187), atol_first=10.0,
+                    rtol_rest=3e-4)
+    return c
+
+
 def layers3d_kat():
     """
     Inputs of seismic/acoustic/acoustic_example.py:26-40,75-79 (3-D layered model, f64, no
@@ -68,3 +88,41 @@ def layers3d_kat():
     rec[:, -1] = 0.0 + 2 * spacing[-1]
     return dict(shape=shape, spacing=spacing, nbl=nbl, space_order=4, vp=v, t0=0.0, tn=1000.0, f0=0.010,
                 src_positions=src, rec_positions=rec, kat=dict(norm_rec=459.1678, rtol=1e-3))
+
+
+def hankel_kat():
+    """
+    The analytic comparison of seismic/acoustic/accuracy.ipynb (cells 2-16, 23): constant 1.5 km/s medium, source
+    at (200, 200) m, one receiver at (260, 260) m, Ricker of 90 Hz delayed by 1.5 / f0, dt = 0.1 ms, nt = 1501.
+    Returns the inputs, the analytic trace of cells 12-13 (2-D Green's function -i pi H0^(2)(k r) times the source
+    spectrum, scaled by the square of the fine grid's spacing) and the numbers the notebook prints.
+    """
+    from scipy.special import hankel2
+    c0, f0, nt, dt = 1.5, 0.09, 1501, 0.1
+    src, rec = np.array([[200.0, 200.0]]), np.array([[260.0, 260.0]])
+    r = float(np.sqrt(((rec - src) ** 2).sum()))
+    # cell 13: the transform runs over 0 .. 3000 ms in 30001 samples, of which the first 1501 are kept
+    n_long, t_long = 30001, 3000.0
+    dt_long = t_long / (n_long - 1)
+    t = np.linspace(-1.5 / f0, t_long - 1.5 / f0, int(t_long / dt_long))          # cell 12, ricker()
+    tt = (np.pi ** 2) * (f0 ** 2) * (t ** 2)
+    spectrum = np.fft.fft((1.0 - 2.0 * tt) * np.exp(-tt))
+    nf = int(n_long / 2 + 1)
+    freq = np.arange(nf) / t_long
+    u_f = np.zeros(nf, dtype=complex)
+    a = np.arange(1, nf - 1)
+    u_f[a] = -1j * np.pi * hankel2(0.0, 2 * np.pi * freq[a] / c0 * r) * spectrum[a]
+    fine_spacing = 0.5
+    analytic = (1.0 / (2.0 * np.pi) * np.real(np.fft.ifft(u_f, n_long)))[:nt] * fine_spacing ** 2
+    printed_errors = {   # cell 23 output: (space order, points per side, spacing) -> RMS error against the analytic trace
+        (2, 201, 2.0): 0.0037682796393557704, (2, 161, 2.5): 0.005812459176798742, (2, 101, 4.0): 0.013011149171741464,
+        (4, 201, 2.0): 0.0003400355796236851, (4, 161, 2.5): 0.0009414704657502754, (4, 101, 4.0): 0.00634686261474598,
+        (6, 201, 2.0): 4.5490650020112585e-05, (6, 161, 2.5): 0.0002068743812472065, (6, 101, 4.0): 0.003742867493048817,
+        (8, 201, 2.0): 4.1758297084644546e-05, (8, 161, 2.5): 7.16374344942322e-05, (8, 101, 4.0): 0.0025733941924053825,
+        (10, 201, 2.0): 4.4878701635970325e-05, (10, 161, 2.5): 4.998218488476813e-05, (10, 101, 4.0): 0.0019484834503388081}
+    return dict(c0=c0, f0=f0, t0w=1.5 / f0, nt=nt, dt=dt, tn=dt * (nt - 1), src=src, rec=rec, nbl=40, analytic=analytic,
+                fine=dict(shape=(801, 801), spacing=(fine_spacing, fine_spacing), space_order=8, dtype=np.float64),
+                kat=dict(numeric_min=-5.349877e-03, numeric_max=+8.529867e-03,        # cell 14 output
+                         analytic_min=-5.322232e-03, analytic_max=+8.543911e-03,
+                         rms_error=1.1265077536675204e-05,                            # cell 16 output
+                         errors=printed_errors, rtol=0.05))

@@ -2,6 +2,9 @@
 Pins the CPU oracle against the reference's own known-answer tests:
   * seismic/inversion/fwi.py:95-97,121     objective 39113, min/max grad -821/2442, 5th GD objective 3828 (atol 10)
   * seismic/acoustic/acoustic_example.py:75-79   ||rec|| = 459.1678 (f64, no free surface, rtol 1e-3)
+  * seismic/tutorials/03_fwi.ipynb cell 24     objective history 57285.10 ... 5786.19 of five descent steps
+  * seismic/acoustic/accuracy.ipynb cells 14, 16, 23   extrema of the fine-grid trace, its RMS distance from the
+    analytic (Hankel function) solution, and the RMS errors of space orders 2 .. 10 on three coarser grids
 plus unit pins of the constants (FD weights vs sympy, CFL dt, sponge centre value of
 seismic/test_seismic_utils.py:17-36).
 """
@@ -9,7 +12,7 @@ import numpy as np
 import pytest
 
 from oracle import oracle as orc
-from kat_setups import circle_kat, layers3d_kat
+from kat_setups import circle_kat, circle_notebook_kat, hankel_kat, layers3d_kat
 
 
 def test_fd_weights_match_sympy():
@@ -90,6 +93,28 @@ def test_kat_circle_fwi():
     assert np.isclose(history[-1], k["objective_it5"], atol=k["atol"], rtol=0)
 
 
+def test_kat_circle_notebook_history():
+    """seismic/tutorials/03_fwi.ipynb cell 24: objective of five gradient-descent steps, shots at 30 m."""
+    c = circle_notebook_kat()
+    prob = orc.Problem(c["vp_true"], c["spacing"], c["nbl"], c["space_order"], dt=c["dt"])
+    dt = prob.critical_dt
+    assert dt == np.float32(1.4)
+    nt, tv = orc.time_axis(c["t0"], c["tn"], float(dt))
+    assert nt == 716
+    wavelet = orc.ricker(c["f0"], tv).astype(np.float32).reshape(nt, 1)
+    vp0 = orc.pad_vp(c["vp_init"], c["nbl"]).astype(np.float32)
+    history = []
+    for it in range(5):
+        phi, direction = _circle_fwi_gradient(c, prob, vp0, wavelet, dt)
+        history.append(phi)
+        alpha = np.float32(.05 / direction.max())
+        vp0 = np.clip(vp0 + alpha * direction, c["vmin"], c["vmax"]).astype(np.float32)
+    print("notebook KAT history:", history)
+    k = c["kat"]
+    assert np.isclose(history[0], k["history"][0], atol=k["atol_first"], rtol=0)
+    np.testing.assert_allclose(history[1:], k["history"][1:], rtol=k["rtol_rest"], atol=0)
+
+
 @pytest.mark.slow
 def test_kat_layers3d_forward_f64():
     """seismic/acoustic/acoustic_example.py:75-79, (fs=False, 459.1678, float64)."""
@@ -155,3 +180,35 @@ def test_born_is_the_derivative_of_forward_and_adjoint_of_gradient():
     lhs, rhs = float(np.sum(lin * r)), float(np.sum(g * dm))
     print("<J dm, r> =", lhs, " <dm, J^T r> =", rhs)
     assert abs(lhs - rhs) <= 1e-9 * max(abs(lhs), abs(rhs))
+
+
+def _hankel_trace(k, shape, spacing, so, dtype):
+    prob = orc.Problem(np.full(shape, k["c0"], dtype=dtype), spacing, k["nbl"], so, dtype=dtype, dt=k["dt"])
+    tv = np.linspace(0.0, k["tn"], k["nt"])
+    w = orc.ricker(k["f0"], tv, t0=k["t0w"]).astype(dtype).reshape(k["nt"], 1)
+    return prob.forward(k["src"], w, k["rec"], dt=k["dt"])[0][:, 0].astype(np.float64)
+
+
+@pytest.mark.slow
+def test_kat_analytic_hankel_fine_grid():
+    """accuracy.ipynb cells 7-16: 801 x 801 points of 0.5 m, float64, space order 8."""
+    k = hankel_kat()
+    a, kat = k["analytic"], k["kat"]
+    assert np.isclose(a.min(), kat["analytic_min"], rtol=1e-6) and np.isclose(a.max(), kat["analytic_max"], rtol=1e-6)
+    f = k["fine"]
+    r = _hankel_trace(k, f["shape"], f["spacing"], f["space_order"], f["dtype"])
+    print("fine grid: min %.6e max %.6e" % (r.min(), r.max()))
+    assert np.isclose(r.min(), kat["numeric_min"], rtol=1e-5) and np.isclose(r.max(), kat["numeric_max"], rtol=1e-5)
+    err = np.linalg.norm(a[:-1] - r[:-1], 2) / np.sqrt(k["nt"])          # cell 16
+    print("rms error", err)
+    assert np.isclose(err, kat["rms_error"], rtol=kat["rtol"])
+
+
+def test_kat_analytic_hankel_space_orders():
+    """accuracy.ipynb cell 23: float32, space orders 2 .. 10 on grids of 2, 2.5 and 4 m."""
+    k = hankel_kat()
+    a = k["analytic"] / k["fine"]["spacing"][0] ** 2
+    for (so, nn, h), want in sorted(k["kat"]["errors"].items()):
+        r = _hankel_trace(k, (nn, nn), (h, h), so, np.float32)
+        err = np.linalg.norm(r[:-1] / h ** 2 - a[:-1], 2) / np.sqrt(k["nt"] - 1)
+        assert np.isclose(err, want, rtol=k["kat"]["rtol"]), (so, nn, err, want)
