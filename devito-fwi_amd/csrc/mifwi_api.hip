@@ -700,9 +700,10 @@ static void fill_stats(Plan &p, double ms, double steps, int nshots, double byte
     p.stats.gpointss = ms > 0 ? p.stats.points / (ms * 1e-3) / 1e9 : 0.0;
     p.stats.algorithmic_bytes = p.stats.points * bytes_per_point * (p.esize / 4.0);
     p.stats.launches = launches;
-    p.stats.kernel_kind = p.loop_persist ? 3 : p.kind;
+    p.stats.kernel_kind = p.loop_persist ? 3 : p.loop_persist_tti ? 5 : p.kind;
     (backward ? p.stats.bwd_kernel_kind : p.stats.fwd_kernel_kind) = p.stats.kernel_kind;
     p.loop_persist = false;
+    p.loop_persist_tti = false;
     p.stats.device_bytes = p.device_bytes;
     p.stats.ckpt_steps = p.ck_K > 0 ? p.ck_nc : 0;
     p.stats.ckpt_segment = p.ck_K;
@@ -1908,6 +1909,96 @@ static int l2_misfit_noalloc(int nshots, long n, const void *syn, const void *ob
 }
 
 // ---- TTI ---------------------------------------------------------------------------------------
+// Can 2-D TTI time loops of this plan run as one launch each (kernels_persist_tti2d.hip)?  Decided once, at the first
+// mifwi_tti_set_model, because it fixes the tile shape: float32, space order 4 or 8, the full GPU with its 8 XCDs,
+// and every 32 x 32 tile of a shot resident on one XCD for each of the three variants of the kernel.
+static bool tti_whole_loop_possible(Plan &p)
+{
+    if (!p.persist || p.kind != 1 || p.esize != 4 || p.xcds != 8 || p.ncu % 8 != 0) return false;
+    if (p.L.R != 2 && p.L.R != 4) return false;
+    if (p.cfg.flags & (MIFWI_FLAG_ASYNC | MIFWI_FLAG_NO_GRAPH | MIFWI_FLAG_GENERIC)) return false;
+    if (p.cfg.nt < 3 || (unsigned long long)p.L.field * 12ull >= (1ull << 31)) return false;
+    if (const char *env = getenv("MIFWI_TTI_PERSIST"))
+        if (atoi(env) == 0) return false;
+    const int ntiles = ((p.L.n[1] + 31) / 32) * ((p.L.n[2] + 31) / 32);
+    for (int mode = 0; mode < 3; ++mode) {
+        if (p.persist_tti_bpc[mode] < 0) p.persist_tti_bpc[mode] = persist_tti2d_blocks_per_cu(p.L.R, mode);
+        if (p.persist_tti_bpc[mode] * (p.ncu / 8) < ntiles) return false;
+    }
+    return true;
+}
+
+// mode 0 forward, 1 adjoint, 2 gradient; `sampled`: the point set the loop interpolates, or null
+static bool tti_persist_eligible(Plan &p, int mode, const SparseSet *sampled)
+{
+    if (!p.tti_whole_loop || !(p.tile_tx == 32 && p.tile_tz == 32)) return false;
+    if (sampled && sampled->max_own > 64) return false;   // a tile samples at most 64 points on this path
+    if (p.persist_skip > 0) {
+        --p.persist_skip;
+        return false;
+    }
+    (void)mode;
+    return true;
+}
+
+// Queue the launches that run a whole TTI loop (groups of 8 shots, one shot per XCD), the check of the tiles' step
+// counts behind each, and the read-back of the abort flag.  fu / fv: rotating levels [shots][3][field] of the two
+// fields; save_u / save_v: [shots][nt][field] or null; su / sv: saved background fields of the gradient loop or null.
+template <typename T>
+static int enqueue_persist_tti(Plan &p, int nshots, int mode, float *fu, float *fv, float *save_u, float *save_v,
+                               const float *su, const float *sv, const TtiParams<T> &tq, int &launches)
+{
+    const Layout &L = p.L;
+    const int ntiles = p.ntx * p.ntz;
+    const size_t nsync = (size_t)8 * ntiles + 16 + 4;
+    int rc;
+    if (!p.d_psync) {
+        if ((rc = dev_alloc(p, (void **)&p.d_psync, nsync * sizeof(int), true))) return rc;
+        MIFWI_HIP(hipHostMalloc((void **)&p.h_abort, sizeof(int), hipHostMallocDefault));
+    }
+    MIFWI_HIP(hipMemsetAsync(p.d_psync, 0, nsync * sizeof(int), p.stream));
+    const size_t ngroup_words = (size_t)8 * ntiles + 16;
+    PersistTtiArgs q{};
+    q.a = base2d(p, nshots);
+    if (mode == 0) {
+        set_inject(q.a, p.src, p);
+        set_interp(q.a, p.rec, p.d_rec);
+    } else {
+        set_inject(q.a, p.rec, p);
+        if (mode == 1) set_interp(q.a, p.src, p.d_srca);
+    }
+    q.et = (const float *)tq.et, q.dl = (const float *)tq.dl, q.ct = (const float *)tq.ct, q.st = (const float *)tq.st;
+    for (int j = 1; j <= tq.p; ++j) q.a1[j] = (float)tq.a[j];
+    q.ihx = (float)tq.ih[1], q.ihz = (float)tq.ih[2];
+    q.rot_u = fu, q.rot_v = fv;
+    const long S = p.cfg.max_shots;
+    q.comb_a = (float *)p.tti_tmp, q.comb_b = (float *)p.tti_tmp + 2 * S * L.field;
+    q.field = L.field;
+    q.forward = mode == 0 ? 1 : 0;
+    q.nsteps = p.cfg.nt - 2;
+    q.save_u = save_u, q.save_v = save_v, q.save_shot_stride = (long)p.cfg.nt * L.field;
+    q.su = su, q.sv = sv, q.s_shot_stride = (long)p.cfg.nt * L.field;
+    q.grad = (float *)p.d_grad, q.g_shot_stride = L.field;
+    q.done = p.d_psync;
+    q.counter = p.d_psync + 8 * ntiles;
+    q.abort_flag = q.counter + 16;
+    q.spin_limit = p.persist_spin;
+    q.drop_slot = -1;
+    if (const char *env = getenv("MIFWI_PERSIST_DROP_SLOT")) q.drop_slot = atoi(env);   // tests
+    const int resident = p.persist_tti_bpc[mode] * (p.ncu / 8);
+    launches = 0;
+    for (int s0 = 0; s0 < nshots; s0 += 8) {
+        if (s0 > 0) MIFWI_HIP(hipMemsetAsync(p.d_psync, 0, ngroup_words * sizeof(int), p.stream));
+        q.a.shot0 = s0;
+        q.a.nshots = std::min(8, nshots - s0);
+        if ((rc = launch_persist_tti2d(p, q, mode, std::min(resident, ntiles + 16), p.stream))) return rc;
+        if (p.persist_check && (rc = launch_persist2d_check(q.done, q.a.nshots * ntiles, q.nsteps, q.abort_flag, p.stream))) return rc;
+        launches += 1;
+    }
+    MIFWI_HIP(hipMemcpyAsync(p.h_abort, q.abort_flag, sizeof(int), hipMemcpyDeviceToHost, p.stream));
+    return MIFWI_OK;
+}
+
 template <typename T>
 static int tti_set_model(Plan &p, const void *eps, const void *delta, const void *theta, const void *phi)
 {
@@ -1918,7 +2009,21 @@ static int tti_set_model(Plan &p, const void *eps, const void *delta, const void
         return fail(MIFWI_EINVAL, "TTI is not available with a free surface or the OT4 kernel");
     if (!eps || !delta || !theta) return fail(MIFWI_EINVAL, "epsilon, delta and theta are required");
     int rc;
-    if (p.kind == 1 && !p.tti_par && !getenv("MIFWI_2D_TX")) {
+    if (p.kind == 1 && !p.tti_par && !getenv("MIFWI_2D_TX") && tti_whole_loop_possible(p)) {
+        // whole time loops in one launch (kernels_persist_tti2d.hip): that kernel works on 32 x 32 tiles
+        p.tti_whole_loop = true;
+        if (!(p.tile_tx == 32 && p.tile_tz == 32)) {
+            clear_graphs(p);
+            p.tile_tx = 32, p.tile_tz = 32;
+            p.ntx = (p.L.n[1] + 31) / 32, p.ntz = (p.L.n[2] + 31) / 32;
+            if (p.have_geometry) {   // the sparse tables are per tile: rebuild them from the kept coordinates
+                if ((rc = build_sparse<T>(p, p.src, (const T *)p.geo_src.data(), p.cfg.nsrc, p.geom_shots, 1))) return rc;
+                if ((rc = build_sparse<T>(p, p.rec, (const T *)p.geo_rec.data(), p.cfg.nrec,
+                                          p.geo_rec_per_shot ? p.geom_shots : 1, p.geo_rec_per_shot ? 1 : 0)))
+                    return rc;
+            }
+        }
+    } else if (p.kind == 1 && !p.tti_par && !getenv("MIFWI_2D_TX")) {
         // The TTI kernel holds two fields and four product arrays of a tile in LDS, so it runs best on small
         // tiles: 8 x 32 was the fastest shape at space orders up to 8 for every batch size, and at higher
         // orders up to about three 32 x 32 tiles per CU (measured on MI355X, Marmousi-II grid: 2 shots at
@@ -2136,6 +2241,33 @@ static int tti_run(Plan &p, int nshots, int mode, int save)
     MIFWI_HIP(hipMemsetAsync(vals_out, 0, (size_t)nshots * nt * std::max(1, itp.npoint) * sizeof(T), p.stream));
     TtiLoop<T> loop(p, nshots);
     if ((rc = loop.prepare(&inj, vals_in))) return rc;
+    if (!ck && loop.tiled && tti_persist_eligible(p, mode, &itp)) {
+        // the whole loop as one launch per group of 8 shots: the fields step on their three rotating levels and, when
+        // saving, stream a copy of every new level into the saved arrays (whose levels 0 and 1 nobody ever writes)
+        T *ru = (T *)(mode == 0 ? p.tti_fwd : p.tti_adj), *rv = ru + S * 3 * L.field;
+        if (in_save) {
+            MIFWI_HIP(hipMemsetAsync(ru, 0, (size_t)nshots * 3 * L.field * sizeof(T), p.stream));
+            MIFWI_HIP(hipMemsetAsync(rv, 0, (size_t)nshots * 3 * L.field * sizeof(T), p.stream));
+        }
+        float *sv_u = in_save ? (float *)p.tti_save : nullptr, *sv_v = in_save ? (float *)p.tti_save + S * (long)nt * L.field : nullptr;
+        auto whole_loop = [&](int &n) -> int {
+            return enqueue_persist_tti<T>(p, nshots, mode, (float *)ru, (float *)rv, sv_u, sv_v, nullptr, nullptr, loop.q, n);
+        };
+        int launches = 0;
+        float ms = 0;
+        if ((rc = timed_loop(p, nullptr, whole_loop, launches, ms, mode == 1))) return rc;
+        if (*p.h_abort) {   // a wait ran out, or a tile had not counted all its steps: this loop anew, a kernel per step
+            p.persist_skip = p.persist_backoff;
+            p.persist_backoff = std::min(4096, 2 * p.persist_backoff);
+            p.stats.persist_fallbacks += 1;
+            return tti_run<T>(p, nshots, mode, save);
+        }
+        p.loop_persist_tti = true;
+        fill_stats(p, ms, nt - 2, nshots, 2 * 20.0 + 6 * 4.0, launches, mode == 1);
+        if (save) p.tti_save_valid = true, p.tti_save_shots = nshots;
+        (mode == 0 ? p.tti_fwd_valid : p.tti_adj_valid) = true;
+        return MIFWI_OK;
+    }
     auto enqueue = [&](int &launches) -> int {
         for (int step = 1; step <= nt - 2; ++step) {
             const int time = mode == 0 ? step : nt - 1 - step;
@@ -2261,6 +2393,26 @@ static int tti_gradient(Plan &p, int nshots, const void *residual, void *grad, i
     TtiLoop<T> loop(p, nshots);
     if ((rc = loop.prepare(&p.rec, (const T *)p.d_res))) return rc;
     if (ck && loop.tiled && (rc = prepare_injection<T>(p, p.src, p.d_wavelet_ck, nshots))) return rc;   // recomputation
+    if (!ck && loop.tiled && tti_persist_eligible(p, 2, nullptr)) {
+        auto whole_loop = [&](int &n) -> int {
+            return enqueue_persist_tti<T>(p, nshots, 2, (float *)bp, (float *)br, nullptr, nullptr, (const float *)su, (const float *)sv,
+                                          loop.q, n);
+        };
+        int launches = 0;
+        float ms = 0;
+        if ((rc = timed_loop(p, nullptr, whole_loop, launches, ms, true))) return rc;
+        if (*p.h_abort) {
+            p.persist_skip = p.persist_backoff;
+            p.persist_backoff = std::min(4096, 2 * p.persist_backoff);
+            p.stats.persist_fallbacks += 1;
+            return tti_gradient<T>(p, nshots, residual, grad, accumulate);
+        }
+        p.loop_persist_tti = true;
+        fill_stats(p, ms, nt - 2, nshots, 2 * 20.0 + 6 * 4.0 + 2 * 4.0 + 8.0, launches, true);
+        p.tti_adj_valid = true;
+        if ((rc = deliver_grid<T>(p, p.d_grad, grad, nshots, accumulate))) return rc;
+        return finish(p);
+    }
     auto enqueue = [&](int &launches) -> int {
         int r;
         if (!ck) {

@@ -187,11 +187,14 @@ struct Plan {
     int persist_backoff = 64;          // and how many the next abandoned launch will cost (doubles, up to 4096)
     int persist_spin = 1 << 21;        // polls of a neighbour's counter before a loop is abandoned (MIFWI_PERSIST_SPIN)
     int persist_bpc[2] = {-1, -1};     // resident blocks per CU of the plain / gradient variant, -1 = not asked yet
+    int persist_tti_bpc[3] = {-1, -1, -1};   // the same for the whole-loop TTI kernel: forward, adjoint, gradient
     bool persist_check = true;         // a one-block kernel behind every whole-loop launch verifies the tiles' step counts
     int xcds = 0;                      // XCDs blocks are dealt to on this device (census at plan creation); the whole-loop kernel needs 8
     int *d_psync = nullptr;            // per-tile step counters [8][tiles], blocks taken per XCD [16], abort flag
     int *h_abort = nullptr;            // pinned host copy of the abort flag
     bool loop_persist = false;         // the loop whose statistics are being filled in ran that way
+    bool tti_whole_loop = false;       // 2-D TTI loops of this plan run as one launch each (decided at the first tti_set_model)
+    bool loop_persist_tti = false;     // ... and the loop whose statistics are being filled in did
 
     // captured time loops: (loop kind, nshots, variant a, variant b, group) -> executable graph + launches
     std::map<std::tuple<int, int, int, int, int>, std::pair<hipGraphExec_t, int>> graphs;
@@ -460,6 +463,30 @@ int launch_persist2d(const Plan &p, const Persist2DArgs &q, bool grad, int block
 int launch_persist2d_check(const int *done, int ncounters, int nsteps, int *abort_flag, hipStream_t stream);
 // XCDs the current device deals blocks to (ids 0 .. n-1 seen by a census launch), 0 when the ids have gaps
 int persist2d_xcd_count(hipStream_t stream);
+
+// ---- whole time loops of small 2-D TTI batches in one launch (kernels_persist_tti2d.hip) -------
+struct PersistTtiArgs {
+    Step2DArgs a;          // constants, model (m, eta), injection and interpolation tables
+    const float *et, *dl, *ct, *st;   // haloed parameter fields: 1 + 2 eps, sqrt(1 + 2 delta), cos / sin of the tilt
+    float a1[kMaxR / 2 + 1];          // centred first-derivative weights
+    float ihx, ihz;                   // 1 / spacing
+    float *rot_u, *rot_v;  // [shots][3][field] rotating levels of the two fields being advanced
+    float *comb_a, *comb_b;   // backward loops: [shots][2][field] the stencilled combinations et p + dl r, dl p + r of the
+                              // newest level, two alternating slots (zero before the loop)
+    long field;
+    int forward;           // 1: time runs 1 .. nt-2, 0: nt-2 .. 1
+    int nsteps;
+    float *save_u, *save_v;   // forward loops: every new level is also streamed to save_*[shot][time + 1], or null
+    long save_shot_stride;    // elements between the shots of save_u / save_v (levels are `field` apart)
+    const float *su, *sv;     // gradient loops: saved background fields, [shot][time]
+    long s_shot_stride;
+    float *grad;              // gradient sums [shot][field]
+    long g_shot_stride;
+    int *done, *counter, *abort_flag;   // as in Persist2DArgs
+    int spin_limit, drop_slot;
+};
+int persist_tti2d_blocks_per_cu(int R, int mode);
+int launch_persist_tti2d(const Plan &p, const PersistTtiArgs &q, int mode, int blocks_per_xcd, hipStream_t stream);
 
 // ---- 2.5-D fast path for 3-D grids (kernels_3d.hip) -------------------------------------------
 struct Step3DArgs {

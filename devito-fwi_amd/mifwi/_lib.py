@@ -48,7 +48,8 @@ class _Stats(ctypes.Structure):
 KERNEL_NAMES = {0: ("step_generic_kernel", "step_generic_kernel<GRAD>"),
                 1: ("step2d_kernel", "step2d_kernel<GRAD>"),
                 2: ("step3d_kernel", "step3d_kernel<GRAD>"),
-                3: ("persist2d_kernel", "persist2d_kernel<GRAD>")}
+                3: ("persist2d_kernel", "persist2d_kernel<GRAD>"),
+                5: ("persist_tti2d_kernel", "persist_tti2d_kernel<BWD>")}
 
 
 _LIB = None

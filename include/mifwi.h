@@ -140,7 +140,7 @@ typedef struct mifwi_stats {
     int32_t launches;       /* kernel launches of the last call                               */
     int32_t fwd_launches;   /* kernel launches of the last forward time loop                  */
     int32_t bwd_launches;   /* kernel launches of the last backward time loop                 */
-    int32_t kernel_kind;    /* 0 generic, 1 tiled 2-D, 2 2.5-D 3-D, 3 whole 2-D loop per launch */
+    int32_t kernel_kind;    /* 0 generic, 1 tiled 2-D, 2 2.5-D 3-D, 3 whole 2-D loop per launch, 5 whole 2-D TTI loop per launch */
     int64_t device_bytes;   /* device memory currently held by the plan                       */
     int32_t ckpt_steps;     /* leading time steps whose wavefield is kept as checkpoints and propagated a second
                                time by the gradient (0: every level is stored)                 */
