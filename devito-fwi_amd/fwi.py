@@ -159,6 +159,24 @@ def _mute_factors_device(model, geometry, shots, device):
     return t
 
 
+_MASK_DEV = {}
+
+
+def _mask_device(mask, device):
+    """float64 tensor of the gradient mask on `device`, kept while the same array is passed with the same content."""
+    import torch
+    a = np.ascontiguousarray(mask, dtype=np.float64)
+    key = (id(mask), a.shape, str(device))
+    finger = float(a.reshape(-1)[::97].sum())
+    hit = _MASK_DEV.get(key)
+    if hit is None or hit[0] != finger:
+        if len(_MASK_DEV) > 8:
+            _MASK_DEV.clear()
+        hit = (finger, torch.as_tensor(a).to(device), mask)
+        _MASK_DEV[key] = hit
+    return hit[1]
+
+
 def _all_reduce_sum_device(packed):
     """Sum a float64 tensor over the ranks where it lives: RCCL for a GPU tensor under the nccl backend;
     under gloo (CPU rehearsals) it travels through the host."""
@@ -196,18 +214,21 @@ def _all_reduce_sum(fval, arrays):
 # ---------------------------------------------------------------------------------------------
 # batched engine access
 # ---------------------------------------------------------------------------------------------
-def _batch_entry(geometry, shots):
-    """GPU plan holding `len(shots)` shots of this acquisition, loaded with the current model."""
+def _batch_entry(geometry, shots, dt=None):
+    """GPU plan holding `len(shots)` shots of this acquisition, loaded with the current model.  `dt`: the model's
+    critical time step when the caller has it at hand (forming it takes a pass over the velocity model)."""
     from mifwi import engine
+    from seismic.source import TimeAxis
     model = geometry.model
     model._initialize_bcs(bcs="damp")
+    dt = model.critical_dt if dt is None else dt
     # modelling always runs on the model's own time axis: the per-shot geometries the reference builds
     # (fwi.py:73-76,185-188) do not inherit geometry.resample(), which only affects the misfit sampling
-    nt = _shot_geometry(geometry, 0).nt
+    nt = TimeAxis(start=geometry.t0, stop=geometry.tn, step=dt).num
     from mifwi import FLAG_FREE_SURFACE, FLAG_SAVE_F16
     flags = (FLAG_FREE_SURFACE if getattr(model, 'fs', False) else 0) | (FLAG_SAVE_F16 if SAVE_HALF else 0)
     entry = engine.get_plan(model.grid.shape, model.spacing, model.grid.origin, model.space_order, nt,
-                            model.critical_dt, 1, geometry.nrec, max_shots=len(shots), dtype=model.dtype,
+                            dt, 1, geometry.nrec, max_shots=len(shots), dtype=model.dtype,
                             flags=flags)
     vp = model.vp.data
     if np.ndim(vp) == 0:
@@ -223,9 +244,22 @@ def _batch_entry(geometry, shots):
     return entry
 
 
-def _wavelet(geometry):
-    """(nt, 1) source time function of one shot (all shots share type, f0 and filter)."""
-    return _shot_geometry(geometry, 0).src.data
+_WAVELETS = {}
+
+
+def _wavelet(geometry, dt=None):
+    """(nt, 1) source time function of one shot (all shots share type, f0 and filter).  It depends on the time
+    axis and the source parameters only, so it is formed once per such set (through the same classes as ever)."""
+    dt = geometry.model.critical_dt if dt is None else dt
+    key = (geometry.src_type, geometry.f0, geometry._t0w, geometry._a, float(geometry.t0), float(geometry.tn), float(dt),
+           id(geometry._filter), geometry.model.dim, str(geometry.model.dtype))
+    hit = _WAVELETS.get(key)
+    if hit is None or hit[1] is not geometry._filter:
+        if len(_WAVELETS) > 64:
+            _WAVELETS.clear()
+        hit = (np.ascontiguousarray(_shot_geometry(geometry, 0).src.data), geometry._filter)
+        _WAVELETS[key] = hit
+    return hit[0]
 
 
 # Subtracting the direct wave from both synthetic and observed data (reference fwi.py:148-150)
@@ -250,6 +284,8 @@ def clear_caches():
     """Forget the device-resident copies of observed data."""
     _device_data.clear()
     _resampled_data.clear()
+    _MASK_DEV.clear()
+    _WAVELETS.clear()
 
 
 def _resident_batch(plan, objs, shots, dtype):
@@ -330,17 +366,17 @@ def _grid_outputs(plan, ns, dtype):
     return torch.empty(shape, dtype=dtype, device='cuda'), torch.empty(shape, dtype=dtype, device='cuda')
 
 
-def _compute_batch(geometry, shots, obs, direct_wave, misfit_func, calc_grad):
+def _compute_batch(geometry, shots, obs, direct_wave, misfit_func, calc_grad, dt=None):
     """Objective pieces of the shots `shots` (indices into the survey) as one GPU batch:
     (fvals per shot, residuals (ns, nt, nrec), padded-grid gradients (ns, *grid) or None,
     illumination likewise).  With the least-squares misfit the residual is formed on the device
     from device-resident observed data and stays there until somebody reads it; with any other
     misfit function the misfit runs on the host between the two passes."""
     model = geometry.model
-    entry = _batch_entry(geometry, shots)
+    entry = _batch_entry(geometry, shots, dt)
     plan = entry.plan
     ns = len(shots)
-    wavelet = _wavelet(geometry)
+    wavelet = _wavelet(geometry, dt)
     if misfit_func is least_square and (direct_wave is None or FUSE_DIRECT_WAVE):
         import torch
         obs_dev = _resident_batch(plan, obs, shots, model.dtype)
@@ -477,11 +513,17 @@ def fwi_obj_single(geometry, obs, misfit_func, direct_wave=None, resample_dt=Non
     return fval, crop_grad, residual.data, illum
 
 
-def _same_sampling(geometry, objs):
-    dt = geometry.model.critical_dt
-    if not np.isclose(geometry.dt, dt):
+def _close(a, b):
+    """np.isclose(a, b) for two scalars (its defaults), without its array machinery."""
+    a, b = float(a), float(b)
+    return abs(a - b) <= 1e-8 + 1e-5 * abs(b)
+
+
+def _same_sampling(geometry, objs, dt=None):
+    dt = geometry.model.critical_dt if dt is None else dt
+    if not _close(geometry.dt, dt):
         return False
-    return all(o is None or np.isclose(o.time_range.step, dt) for o in objs)
+    return all(o is None or _close(o.time_range.step, dt) for o in objs)
 
 
 def fwi_obj_multi(geometry, obs, misfit_func, direct_wave=None, mask=None, precond=True, calc_grad=False):
@@ -500,8 +542,9 @@ def fwi_obj_multi(geometry, obs, misfit_func, direct_wave=None, mask=None, preco
     grad = np.zeros(model.shape)
     illum = np.zeros(model.shape)
     residuals = _ResidualList(nsrc)
+    dt_model = model.critical_dt      # once per evaluation: a pass over the velocity model
     if mine and not _same_sampling(geometry, [obs[i] for i in mine] +
-                                   ([direct_wave[i] for i in mine] if direct_wave is not None else [])):
+                                   ([direct_wave[i] for i in mine] if direct_wave is not None else []), dt_model):
         # resampled data: shot-by-shot, as the reference does it
         for i in mine:
             f_, g_, r_, il_ = fwi_obj_single(_shot_geometry(geometry, i), obs[i], misfit_func,
@@ -513,7 +556,7 @@ def fwi_obj_multi(geometry, obs, misfit_func, direct_wave=None, mask=None, preco
                 grad += g_
                 illum += il_
     elif mine:
-        fvals, res_b, g_b, il_b = _compute_batch(geometry, mine, obs, direct_wave, misfit_func, calc_grad)
+        fvals, res_b, g_b, il_b = _compute_batch(geometry, mine, obs, direct_wave, misfit_func, calc_grad, dt_model)
         crop = model.physical_slices
         for k, i in enumerate(mine):
             fval += float(fvals[k])
@@ -534,7 +577,7 @@ def fwi_obj_multi(geometry, obs, misfit_func, direct_wave=None, mask=None, preco
             if precond:
                 g_sum = g_sum / torch.sqrt(il_sum + 1e-30)
             if mask is not None:
-                g_sum = g_sum * torch.as_tensor(np.ascontiguousarray(mask, dtype=np.float64), device=g_sum.device)
+                g_sum = g_sum * _mask_device(mask, g_sum.device)
             host = torch.cat([packed[:1], g_sum.reshape(-1)]).cpu().numpy()
             return float(host[0]), host[1:].copy(), residuals
         if calc_grad:

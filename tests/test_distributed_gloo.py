@@ -43,7 +43,7 @@ def _problem():
                                       vp_true=vp_true, vp_init=vp_init)
 
 
-def _oracle_batch(geometry, shots, obs, direct_wave, misfit_func, calc_grad):
+def _oracle_batch(geometry, shots, obs, direct_wave, misfit_func, calc_grad, dt=None):
     """Stand-in for fwi._compute_batch backed by the CPU oracle."""
     from oracle import oracle as orc
     model = geometry.model
