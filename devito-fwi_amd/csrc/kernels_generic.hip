@@ -658,6 +658,66 @@ template int launch_l2_misfit<double>(const Plan &, const double *, const double
                                       double *);
 
 // ------------------------------------------------------------------------------------------
+// Tail of the multi-shot objective.  mute_sum: crop each shot's padded-grid gradient and illumination to the
+// physical grid, scale by that shot's source/receiver mute factor and add the shots up in float64, in shot order
+// and without contracting the product into the sum -- the arithmetic of `grad += crop(g) * mute` on the host
+// (fwi.py:164-171,190-193).  precondition: g / sqrt(illum + 1e-30) and the mask (fwi.py:200-204).
+// ------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void mute_sum_kernel(CropMap c, int nshots, const T *g, const T *il, const double *mute,
+                                                       double *gs, double *ils)
+{
+#pragma clang fp contract(off)   // product and sum round separately, as they do on the host
+    const long i = blockIdx.x * 256L + threadIdx.x;
+    if (i >= c.nphys) return;
+    long rem = i, off = 0;
+    for (int d = c.nd - 1; d >= 0; --d) {
+        const long q = rem / c.phys[d];
+        off += (rem - q * c.phys[d] + c.lo[d]) * c.pad_stride[d];
+        rem = q;
+    }
+    double a = 0.0, b = 0.0;
+    for (int s = 0; s < nshots; ++s) {
+        const double m = mute ? mute[(long)s * c.nphys + i] : 1.0;
+        a += (double)g[(long)s * c.field + off] * m;
+        if (il) b += (double)il[(long)s * c.field + off] * m;
+    }
+    gs[i] = a;
+    if (ils) ils[i] = b;
+}
+template <typename T>
+int launch_mute_sum(hipStream_t stream, const CropMap &c, int nshots, const T *g, const T *il, const double *mute,
+                    double *gs, double *ils)
+{
+    const int nb = (int)((c.nphys + 255) / 256);
+    hipLaunchKernelGGL((mute_sum_kernel<T>), dim3(nb), dim3(256), 0, stream, c, nshots, g, il, mute, gs, ils);
+    MIFWI_HIP(hipGetLastError());
+    return MIFWI_OK;
+}
+template int launch_mute_sum<float>(hipStream_t, const CropMap &, int, const float *, const float *, const double *,
+                                    double *, double *);
+template int launch_mute_sum<double>(hipStream_t, const CropMap &, int, const double *, const double *, const double *,
+                                     double *, double *);
+
+__global__ __launch_bounds__(256) void precondition_kernel(long n, const double *g, const double *il, const double *mask,
+                                                           double *out)
+{
+#pragma clang fp contract(off)
+    const long i = blockIdx.x * 256L + threadIdx.x;
+    if (i >= n) return;
+    double v = g[i];
+    if (il) v = v / sqrt(il[i] + 1e-30);
+    if (mask) v = v * mask[i];
+    out[i] = v;
+}
+int launch_precondition(hipStream_t stream, long n, const double *g, const double *il, const double *mask, double *out)
+{
+    hipLaunchKernelGGL(precondition_kernel, dim3((int)((n + 255) / 256)), dim3(256), 0, stream, n, g, il, mask, out);
+    MIFWI_HIP(hipGetLastError());
+    return MIFWI_OK;
+}
+
+// ------------------------------------------------------------------------------------------
 // Half-precision saved levels.  Scale of one shot: 64 / max |injected source term| over the whole run
 // (terms are dt^2 * wavelet * weight / m, the per-step increments of the field at the source cells).
 // The field's peak is about (samples per wavelet period) / 4 such increments in 2-D (12 on Marmousi-II)

@@ -186,6 +186,7 @@ static void destroy(Plan *p)
     dev_free(p->d_dense);
     dev_free(p->d_partial);
     dev_free(p->d_fval);
+    dev_free(p->d_reduce);
     dev_free(p->eta_zero);
     dev_free(p->eta_free);
     for (auto &pair : p->ev)
@@ -623,14 +624,20 @@ static int set_model(Plan &p, const void *vp, const void *damp)
     T *ddamp = dvp + p.L.ngrid;
     int rc;
     const T *vp_dev = (const T *)vp, *damp_dev = (const T *)damp;
+    bool from_host = false;
     if (!is_device_ptr(vp)) {
         if ((rc = copy_any(p, dvp, vp, bytes))) return rc;
         vp_dev = dvp;
+        from_host = true;
     }
     if (damp && !is_device_ptr(damp)) {
         if ((rc = copy_any(p, ddamp, damp, bytes))) return rc;
         damp_dev = ddamp;
+        from_host = true;
     }
+    // pageable host sources must not be reused by the caller before the copy has happened; the kernels below are
+    // ordered behind it on the plan's stream and need no waiting for
+    if (from_host) MIFWI_HIP(hipStreamSynchronize(p.stream));
     if ((rc = launch_prep_model<T>(p, vp_dev, damp_dev, (T *)p.m, (T *)p.eta))) return rc;
     if (p.ck_K > 0 && p.saved_valid) {
         // checkpoints are re-propagated with the model at hand: those of the previous model are of no use now
@@ -644,8 +651,6 @@ static int set_model(Plan &p, const void *vp, const void *damp)
         if ((rc = launch_eta_zero(p, p.eta_zero, p.eta_free))) return rc;
     }
     p.have_model = true;
-    // pageable host sources must not be reused by the caller before the copy has happened
-    MIFWI_HIP(hipStreamSynchronize(p.stream));
     return MIFWI_OK;
 }
 
@@ -1893,6 +1898,63 @@ static int l2_misfit(Plan &p, int nshots, const void *syn, const void *obs, void
     return finish(p);
 }
 
+// ---- tail of the multi-shot objective (fwi.py:164-171,190-204) -------------------------------------
+static int reduce_buffer(Plan &p)
+{
+    if (p.d_reduce) return MIFWI_OK;
+    long ngrid = 1;
+    for (int d = 0; d < p.cfg.ndim; ++d) ngrid *= p.cfg.shape[d];
+    return dev_alloc(p, (void **)&p.d_reduce, (size_t)3 * ngrid * sizeof(double), false);
+}
+
+template <typename T>
+static int sum_shots(Plan &p, int nshots, const void *grad, const void *illum, const double *mute, const int32_t *lo,
+                     const int32_t *phys, double *g_sum, double *il_sum)
+{
+    if (nshots < 1) return fail(MIFWI_EINVAL, "nshots must be at least 1");
+    if (!grad || !g_sum || !lo || !phys) return fail(MIFWI_EINVAL, "null argument");
+    if ((illum == nullptr) != (il_sum == nullptr)) return fail(MIFWI_EINVAL, "illum and il_sum go together");
+    if (!is_device_ptr(grad) || (illum && !is_device_ptr(illum)) || (mute && !is_device_ptr(mute)))
+        return fail(MIFWI_EINVAL, "mifwi_sum_shots reads device arrays");
+    CropMap c{};
+    c.nd = p.cfg.ndim;
+    c.field = 1;
+    c.nphys = 1;
+    for (int d = c.nd - 1; d >= 0; --d) {
+        if (lo[d] < 0 || phys[d] < 1 || lo[d] + phys[d] > p.cfg.shape[d])
+            return fail(MIFWI_EINVAL, "physical window outside the padded grid");
+        c.lo[d] = lo[d];
+        c.phys[d] = phys[d];
+        c.pad_stride[d] = c.field;
+        c.field *= p.cfg.shape[d];
+        c.nphys *= phys[d];
+    }
+    int rc = reduce_buffer(p);
+    if (rc) return rc;
+    double *gs = is_device_ptr(g_sum) ? g_sum : p.d_reduce;
+    double *ils = !il_sum ? nullptr : (is_device_ptr(il_sum) ? il_sum : p.d_reduce + c.field);
+    if ((rc = launch_mute_sum<T>(p.stream, c, nshots, (const T *)grad, (const T *)illum, mute, gs, ils))) return rc;
+    if (gs != g_sum && (rc = copy_any(p, g_sum, gs, (size_t)c.nphys * sizeof(double)))) return rc;
+    if (il_sum && ils != il_sum && (rc = copy_any(p, il_sum, ils, (size_t)c.nphys * sizeof(double)))) return rc;
+    return finish(p);
+}
+
+static int precondition(Plan &p, long n, const double *g, const double *il, const double *mask, double *out)
+{
+    if (n < 0 || !g || !out) return fail(MIFWI_EINVAL, "bad argument");
+    long ngrid = 1;
+    for (int d = 0; d < p.cfg.ndim; ++d) ngrid *= p.cfg.shape[d];
+    if (n > ngrid) return fail(MIFWI_EINVAL, "n exceeds the padded grid");
+    if (!is_device_ptr(g) || (il && !is_device_ptr(il)) || (mask && !is_device_ptr(mask)))
+        return fail(MIFWI_EINVAL, "mifwi_precondition reads device arrays");
+    int rc = reduce_buffer(p);
+    if (rc) return rc;
+    double *o = is_device_ptr(out) ? out : p.d_reduce + 2 * ngrid;
+    if (n > 0 && (rc = launch_precondition(p.stream, n, g, il, mask, o))) return rc;
+    if (o != out && (rc = copy_any(p, out, o, (size_t)n * sizeof(double)))) return rc;
+    return finish(p);
+}
+
 // ---- the entry point that allocates nothing: its body (scratch array and address look-up: top of this file) ---
 template <typename T>
 static int l2_misfit_noalloc(int nshots, long n, const void *syn, const void *obs, void *res, double *fval,
@@ -2698,6 +2760,21 @@ int mifwi_l2_misfit(mifwi_plan *plan, int32_t nshots, const void *syn, const voi
     PLAN_OR_FAIL(plan);
     GUARDED(DISPATCH(l2_misfit<float>(p, nshots, syn, obs, residual_out, fval),
                      l2_misfit<double>(p, nshots, syn, obs, residual_out, fval)));
+}
+
+int mifwi_sum_shots(mifwi_plan *plan, int32_t nshots, const void *grad, const void *illum, const double *mute,
+                    const int32_t *lo, const int32_t *phys_shape, double *g_sum, double *il_sum)
+{
+    PLAN_OR_FAIL(plan);
+    GUARDED(DISPATCH(sum_shots<float>(p, nshots, grad, illum, mute, lo, phys_shape, g_sum, il_sum),
+                     sum_shots<double>(p, nshots, grad, illum, mute, lo, phys_shape, g_sum, il_sum)));
+}
+
+int mifwi_precondition(mifwi_plan *plan, int64_t n, const double *g_sum, const double *il_sum, const double *mask,
+                       double *out)
+{
+    PLAN_OR_FAIL(plan);
+    GUARDED(precondition(p, (long)n, g_sum, il_sum, mask, out));
 }
 
 int mifwi_l2_misfit_noalloc(int32_t dtype, int32_t nshots, int64_t n_per_shot, const void *syn, const void *obs,

@@ -165,6 +165,7 @@ struct Plan {
     size_t dense_elems = 0;
     double *d_partial = nullptr;             // misfit partial sums
     double *d_fval = nullptr;                // [max_shots]
+    double *d_reduce = nullptr;              // [3 * padded grid] shot sums and preconditioned gradient, on first use
 
     // fast paths (float32): kind 1 = tiled 2-D kernel, tiles tile_tx x tile_tz over (x, z);
     // kind 2 = 2.5-D kernel, tiles tile_tx x tile_tz over (y, z), marching x in chunks of xchunk
@@ -314,6 +315,21 @@ constexpr int kMisfitPartials = 64;
 template <typename T>
 int launch_l2_misfit_on(hipStream_t stream, const T *syn, const T *obs, T *res, long n_per_shot, int nshots,
                         double *partial, double *fval);
+
+// physical-grid window of a padded-grid array (the crop of fwi.py:164)
+struct CropMap {
+    int nd;
+    int phys[3], lo[3];
+    long pad_stride[3];
+    long field;   // elements of one shot's padded-grid array
+    long nphys;   // elements of the physical grid
+};
+// gs = sum_s crop(g[s]) * mute[s] (ils likewise from il; il, ils and mute may be null), float64, shot order
+template <typename T>
+int launch_mute_sum(hipStream_t stream, const CropMap &c, int nshots, const T *g, const T *il, const double *mute,
+                    double *gs, double *ils);
+// out = g / sqrt(il + 1e-30) * mask (il null: no division; mask null: no mask)
+int launch_precondition(hipStream_t stream, long n, const double *g, const double *il, const double *mask, double *out);
 
 // ---- TTI propagators (kernels_tti.hip) ----------------------------------------------------------
 template <typename T>

@@ -234,7 +234,14 @@ def _batch_entry(geometry, shots, dt=None):
     if np.ndim(vp) == 0:
         vp = np.full(model.grid.shape, vp, dtype=model.dtype)
     damp = model.damp.data if hasattr(model.damp, 'data') else np.full(model.grid.shape, model.damp, model.dtype)
-    entry.plan.set_model(np.ascontiguousarray(vp, dtype=model.dtype), np.ascontiguousarray(damp, dtype=model.dtype))
+    # the damping profile changes with the model's boundary set-up only: it stays on the device between evaluations
+    damp = np.ascontiguousarray(damp, dtype=model.dtype)
+    dkey = (id(model.damp), damp.shape, float(damp.reshape(-1)[::97].sum(dtype=np.float64)))
+    if getattr(entry, 'damp_key', None) != dkey:
+        import torch
+        entry.damp_dev = torch.as_tensor(damp).to('cuda')
+        entry.damp_key = dkey
+    entry.plan.set_model(np.ascontiguousarray(vp, dtype=model.dtype), entry.damp_dev)
     gkey = (geometry.src_positions[shots].tobytes(), geometry.rec_positions.tobytes())
     if entry.geom_key != gkey:
         entry.plan.set_geometry(geometry.src_positions[shots].reshape(len(shots), 1, model.dim), geometry.rec_positions)
@@ -286,6 +293,7 @@ def clear_caches():
     _resampled_data.clear()
     _MASK_DEV.clear()
     _WAVELETS.clear()
+    _GRID_OUTPUTS.clear()
 
 
 def _resident_batch(plan, objs, shots, dtype):
@@ -296,7 +304,7 @@ def _resident_batch(plan, objs, shots, dtype):
     import torch
     arrays = [objs[i].data for i in shots]
     key = (id(plan),) + tuple(id(a) for a in arrays)
-    finger = tuple(float(np.asarray(a).reshape(-1)[::251].sum(dtype=np.float64)) for a in arrays)
+    finger = tuple(float(np.asarray(a).reshape(-1)[::4099].sum(dtype=np.float64)) for a in arrays)
     hit = _device_data.get(key)
     if hit is not None and hit[0] == finger:
         return hit[1]
@@ -358,12 +366,24 @@ class _ResidualList(object):
         return (self[i] for i in range(len(self)))
 
 
+_GRID_OUTPUTS = {}
+
+
 def _grid_outputs(plan, ns, dtype):
     """Device tensors for the per-shot padded-grid gradients and illuminations of a batch: they are cropped,
-    muted and summed where they are, and only the summed physical-grid arrays ever cross to the host."""
+    muted and summed where they are, and only the summed physical-grid arrays ever cross to the host.  One pair per
+    plan and batch size, overwritten by every evaluation (nothing of it is handed to the caller)."""
     import torch
-    shape = (ns,) + tuple(plan.shape)
-    return torch.empty(shape, dtype=dtype, device='cuda'), torch.empty(shape, dtype=dtype, device='cuda')
+    key = (id(plan), ns, str(dtype))
+    hit = _GRID_OUTPUTS.get(key)
+    if hit is None or hit[0] is not plan:
+        if len(_GRID_OUTPUTS) > 8:
+            _GRID_OUTPUTS.clear()
+        shape = (ns,) + tuple(plan.shape)
+        hit = (plan, torch.empty(shape, dtype=dtype, device='cuda'), torch.empty(shape, dtype=dtype, device='cuda'))
+        _GRID_OUTPUTS[key] = hit
+    hit[1]._mifwi_plan = plan
+    return hit[1], hit[2]
 
 
 def _compute_batch(geometry, shots, obs, direct_wave, misfit_func, calc_grad, dt=None):
@@ -459,7 +479,7 @@ def _resampled(obj, dt):
     (observed and direct-wave gathers are resampled identically at every objective evaluation)."""
     arr = obj.data
     key = (id(arr), float(dt))
-    finger = float(np.asarray(arr).reshape(-1)[::251].sum(dtype=np.float64))
+    finger = float(np.asarray(arr).reshape(-1)[::4099].sum(dtype=np.float64))
     hit = _resampled_data.get(key)
     if hit is not None and hit[0] == finger:
         return hit[1]
@@ -539,8 +559,10 @@ def fwi_obj_multi(geometry, obs, misfit_func, direct_wave=None, mask=None, preco
     nsrc = geometry.nsrc
     mine = shot_partition(nsrc)
     fval = .0
-    grad = np.zeros(model.shape)
-    illum = np.zeros(model.shape)
+    grad = illum = None
+    if calc_grad:
+        grad = np.zeros(model.shape)
+        illum = np.zeros(model.shape)
     residuals = _ResidualList(nsrc)
     dt_model = model.critical_dt      # once per evaluation: a pass over the velocity model
     if mine and not _same_sampling(geometry, [obs[i] for i in mine] +
@@ -564,22 +586,24 @@ def fwi_obj_multi(geometry, obs, misfit_func, direct_wave=None, mask=None, preco
         if calc_grad and type(g_b).__module__.startswith('torch'):
             # device route: crop, mute (per shot, before the sum, as fwi.py:166-171 of the reference does), shot sum,
             # all-reduce, preconditioner and mask on the GPU, in float64 like the host route; one small copy back
+            # (mifwi_sum_shots, mifwi_precondition: the arithmetic of the host route below, bit for bit)
             import torch
-            sl = (slice(None),) + tuple(crop)
+            plan = g_b._mifwi_plan
+            n = int(np.prod(model.shape))
+            packed = torch.empty(1 + 2 * n, dtype=torch.float64, device=g_b.device)
+            g_sum, il_sum = packed[1:1 + n], packed[1 + n:]
             mutes = _mute_factors_device(model, geometry, mine, g_b.device)
-            g_sum = (g_b[sl].double() * mutes).sum(0)
-            il_sum = (il_b[sl].double() * mutes).sum(0)
-            packed = torch.cat([torch.tensor([fval], dtype=torch.float64, device=g_b.device), g_sum.reshape(-1),
-                                il_sum.reshape(-1)])
-            packed = _all_reduce_sum_device(packed)
-            n = g_sum.numel()
-            g_sum, il_sum = packed[1:1 + n].reshape(g_sum.shape), packed[1 + n:].reshape(g_sum.shape)
-            if precond:
-                g_sum = g_sum / torch.sqrt(il_sum + 1e-30)
-            if mask is not None:
-                g_sum = g_sum * _mask_device(mask, g_sum.device)
-            host = torch.cat([packed[:1], g_sum.reshape(-1)]).cpu().numpy()
-            return float(host[0]), host[1:].copy(), residuals
+            dist = _dist()
+            if dist is not None and dist.get_world_size() > 1:
+                packed[:1].fill_(fval)
+            plan.sum_shots(g_b, il_b, mutes, [c.start or 0 for c in crop], model.shape, g_sum=g_sum, il_sum=il_sum)
+            if dist is not None and dist.get_world_size() > 1:
+                packed = _all_reduce_sum_device(packed)
+                g_sum, il_sum = packed[1:1 + n], packed[1 + n:]
+                fval = float(packed[0].item())
+            mask_dev = _mask_device(mask, g_b.device).reshape(-1) if mask is not None else None
+            host = plan.precondition(g_sum, il_sum if precond else None, mask_dev)
+            return fval, host, residuals
         if calc_grad:
             for k, i in enumerate(mine):
                 mute = _mute_factor(model.shape, model.spacing, geometry.src_positions[i], geometry.rec_positions)
@@ -593,6 +617,7 @@ def fwi_obj_multi(geometry, obs, misfit_func, direct_wave=None, mask=None, preco
             grad *= mask
     else:
         fval, _ = _all_reduce_sum(fval, [])
+        grad = np.zeros(model.shape)
     return fval, grad.reshape(-1).astype(np.float64), residuals
 
 

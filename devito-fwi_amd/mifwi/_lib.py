@@ -18,7 +18,7 @@ EXPORTED_SYMBOLS = (
     "mifwi_gradient", "mifwi_l2_misfit_gradient", "mifwi_read_wavefield", "mifwi_write_wavefield",
     "mifwi_get_stats", "mifwi_born", "mifwi_tti_set_model", "mifwi_tti_forward", "mifwi_tti_adjoint",
     "mifwi_tti_born", "mifwi_tti_gradient", "mifwi_l2_misfit", "mifwi_l2_misfit_noalloc",
-    "mifwi_set_pml",
+    "mifwi_set_pml", "mifwi_sum_shots", "mifwi_precondition",
 )
 
 
@@ -100,6 +100,8 @@ def load_library():
     lib.mifwi_set_pml.argtypes = [vp, i32, ctypes.c_double]
     lib.mifwi_l2_misfit.argtypes = [vp, i32, vp, vp, vp, vp]
     lib.mifwi_l2_misfit_noalloc.argtypes = [i32, i32, ctypes.c_int64, vp, vp, vp, vp, vp]
+    lib.mifwi_sum_shots.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp]
+    lib.mifwi_precondition.argtypes = [vp, ctypes.c_int64, vp, vp, vp, vp]
     lib.mifwi_read_wavefield.argtypes = [vp, i32, i32, i32, i32, vp]
     lib.mifwi_write_wavefield.argtypes = [vp, i32, i32, i32, vp]
     lib.mifwi_get_stats.argtypes = [vp, ctypes.POINTER(_Stats)]
@@ -181,8 +183,16 @@ class Plan(object):
 
     # -- plumbing -------------------------------------------------------------------------
     def _check(self, rc):
+        self._ordered = False       # the next call's first tensor argument waits for torch again
         if rc != 0:
             raise MifwiError(rc, self._lib.mifwi_last_error().decode())
+
+    def _order(self, x):
+        """_order_after_torch once per library call: the arguments of one call are gathered without any torch
+        work in between, so the wait for the first of them covers the rest."""
+        if not getattr(self, "_ordered", False):
+            _order_after_torch(x)
+            self._ordered = x.is_cuda
 
     def _in(self, x, shape=None):
         """(pointer, keep-alive) of an input array in the plan dtype."""
@@ -190,7 +200,7 @@ class Plan(object):
             return None, None
         if _is_torch(x):
             assert x.is_contiguous()
-            _order_after_torch(x)
+            self._order(x)
             return ctypes.c_void_p(x.data_ptr()), x
         a = np.ascontiguousarray(x, dtype=self.dtype)
         if shape is not None:
@@ -204,7 +214,7 @@ class Plan(object):
             x = np.empty(shape, dtype=dtype)
         if _is_torch(x):
             assert x.is_contiguous()
-            _order_after_torch(x)
+            self._order(x)
             return ctypes.c_void_p(x.data_ptr()), x
         assert isinstance(x, np.ndarray) and x.flags.c_contiguous and x.dtype == dtype, "bad output array"
         assert x.size == int(np.prod(shape)), "bad output size"
@@ -234,6 +244,9 @@ class Plan(object):
         n = kv.numel() if _is_torch(kv) else kv.size
         assert n == self.ngrid, "vp must cover the padded grid"
         self._check(self._lib.mifwi_set_model(self._h, pv, pd))
+        # device tensors are read by a kernel that may still be queued: their memory must not go back to torch's
+        # allocator before the plan has waited, so they are held until the next model replaces them
+        self._model_keep = (kv, kd)
 
     def set_pml(self, npml, quibar=0.05):
         """Layer width (cells) and strength of a FLAG_PML plan."""
@@ -372,6 +385,33 @@ class Plan(object):
         pf, fval = self._out(fval, (nshots,), np.dtype(np.float64))
         self._check(self._lib.mifwi_l2_misfit(self._h, nshots, ps, po, pr, pf))
         return fval, res
+
+    def sum_shots(self, grad, illum, mute, lo, phys_shape, g_sum=None, il_sum=None):
+        """Shot sums of the cropped, muted per-shot gradients and illuminations (device tensors (nshots, *shape));
+        mute: device float64 (nshots, *phys_shape) or None.  Returns (g_sum, il_sum) float64 over the physical grid
+        (numpy arrays unless tensors are passed in); il_sum is None when illum is."""
+        nshots = int(grad.shape[0])
+        f64 = np.dtype(np.float64)
+        pg, kg = self._in(grad)
+        pi, ki = self._in(illum)
+        pm = ctypes.c_void_p(mute.data_ptr()) if mute is not None else None
+        lo_a = (ctypes.c_int32 * self.ndim)(*[int(v) for v in lo])
+        ph_a = (ctypes.c_int32 * self.ndim)(*[int(v) for v in phys_shape])
+        shape = tuple(int(v) for v in phys_shape)
+        ps, g_sum = self._out(g_sum, shape, f64)
+        pl, il_sum = self._out(il_sum, shape, f64) if illum is not None else (None, None)
+        self._check(self._lib.mifwi_sum_shots(self._h, nshots, pg, pi, pm, lo_a, ph_a, ps, pl))
+        return g_sum, il_sum
+
+    def precondition(self, g_sum, il_sum=None, mask=None, out=None):
+        """g_sum / sqrt(il_sum + 1e-30) * mask on device float64 tensors (il_sum, mask optional); `out` a numpy
+        array (default: a new one) or a device tensor."""
+        n = int(g_sum.numel())
+        self._order(g_sum)
+        ptr = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
+        po, out = self._out(out, (n,), np.dtype(np.float64))
+        self._check(self._lib.mifwi_precondition(self._h, n, ptr(g_sum), ptr(il_sum), ptr(mask), po))
+        return out
 
     def read_wavefield(self, which=0, shot=0, first=0, count=None, out=None):
         nlev = self.nt if which in (0, 7, 8) else 3

@@ -184,7 +184,25 @@ class SeismicModel(GenericModel):
         if field.shape != self.shape:
             raise ValueError("Incorrect input size %s for model %s without or %s with padding"
                              % (field.shape, self.shape, self.grid.shape))
-        return np.pad(field, self.padsizes, mode='edge') if self.nbl else field
+        if not self.nbl:
+            return field
+        return self._pad_into(np.empty(self.grid.shape, dtype=field.dtype), field)
+
+    def _pad_into(self, out, field):
+        """Write `field` (physical shape) into `out` (padded shape) with edge padding, one dimension after the other:
+        what np.pad(mode='edge') returns, without its generic path and without a temporary."""
+        out[self.physical_slices] = field
+        for d, (lo, hi) in enumerate(self.padsizes):
+            n = self.grid.shape[d]
+            idx = [slice(None)] * out.ndim
+            src = list(idx)
+            if lo:
+                idx[d], src[d] = slice(0, lo), slice(lo, lo + 1)
+                out[tuple(idx)] = out[tuple(src)]
+            if hi:
+                idx[d], src[d] = slice(n - hi, n), slice(n - hi - 1, n - hi)
+                out[tuple(idx)] = out[tuple(src)]
+        return out
 
     def _gen_phys_param(self, field, name, space_order, is_param=True, default_value=0):
         if field is None:
@@ -243,6 +261,9 @@ class SeismicModel(GenericModel):
         if isinstance(value, np.ndarray):
             if isinstance(param, Constant):
                 setattr(self, name, self._gen_phys_param(value, name, self.space_order))
+            elif self.nbl and value.shape == self.shape and value.shape != self.grid.shape \
+                    and getattr(param.data, 'shape', None) == self.grid.shape:
+                self._pad_into(param.data, value)
             else:
                 param.data[...] = self._pad(value)
         else:

@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define MIFWI_VERSION 101
+#define MIFWI_VERSION 102
 
 enum {
     MIFWI_OK = 0,
@@ -168,7 +168,9 @@ MIFWI_API int mifwi_synchronize(mifwi_plan *plan);
 
 /* Replaces: the `vp` and `damp` arguments of every Operator.apply
  * (seismic/acoustic/wavesolver.py:109,112; seismic/model.py:13-51,395-400).  vp in km/s and
- * damp are padded-grid arrays; m = 1/vp^2 is formed on the device. */
+ * damp are padded-grid arrays (damp NULL: no damping); m = 1/vp^2 is formed on the device.  Host arrays have been
+ * read when the call returns.  DEVICE arrays are read by a kernel queued on the plan's stream: leave them
+ * unchanged (and allocated) until the next call on the plan that waits -- any modelling call, or mifwi_synchronize. */
 MIFWI_API int mifwi_set_model(mifwi_plan *plan, const void *vp, const void *damp);
 
 /* Replaces: the src_coords / rec_coords arguments (SparseTimeFunction.coordinates,
@@ -230,6 +232,24 @@ MIFWI_API int mifwi_set_pml(mifwi_plan *plan, int32_t npml, double quibar);
  * syn, obs, residual_out: (nshots, nt, nrec), host or device; residual_out may be NULL; fval (nshots) doubles. */
 MIFWI_API int mifwi_l2_misfit(mifwi_plan *plan, int32_t nshots, const void *syn, const void *obs, void *residual_out,
                     double *fval);
+
+/* Replaces: the shot loop of fwi_obj_multi (fwi.py:184-193) over what fwi_obj_single returns per shot
+ * (fwi.py:164-171): crop the padded-grid gradient and illumination to the physical grid, scale by the shot's
+ * source/receiver mute factor (fix_source_illumination, fwi.py:104-129, a table the caller builds once per
+ * survey) and add the shots up -- in float64, in shot order, product rounded before the sum, which is the
+ * arithmetic of `grad += crop(g) * mute` on float64 numpy arrays.  grad, illum: DEVICE arrays (nshots, *shape)
+ * in the plan's dtype as mifwi_gradient writes them (illum and il_sum may both be NULL); mute: DEVICE doubles
+ * (nshots, *phys_shape) or NULL for no muting; lo / phys_shape: first index and extent of the physical grid
+ * inside the padded grid per dimension; g_sum, il_sum (*phys_shape) doubles, host or device. */
+MIFWI_API int mifwi_sum_shots(mifwi_plan *plan, int32_t nshots, const void *grad, const void *illum,
+                              const double *mute, const int32_t *lo, const int32_t *phys_shape, double *g_sum,
+                              double *il_sum);
+
+/* Replaces: the illumination preconditioner and the mask of fwi_obj_multi (fwi.py:200-204):
+ * out = g_sum / sqrt(il_sum + 1e-30) * mask over n doubles.  g_sum, il_sum, mask: DEVICE arrays; il_sum NULL skips
+ * the division, mask NULL the mask; out: host or device (may alias g_sum). */
+MIFWI_API int mifwi_precondition(mifwi_plan *plan, int64_t n, const double *g_sum, const double *il_sum,
+                                 const double *mask, double *out);
 
 /* No counterpart in the reference.  For callers that cannot allocate device memory: code under HIP graph capture,
  * tight loops that must not touch the allocator, harnesses that forbid hipMalloc.  The same computation and the
