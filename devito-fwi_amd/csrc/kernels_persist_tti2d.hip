@@ -26,7 +26,8 @@
 //   3. after one barrier every thread updates its four points of both fields, adds the injected terms, stores the new
 //      levels, and -- gradient loop -- adds the correlation with the saved background levels to sums it keeps in
 //      registers for the whole loop.
-// Arithmetic and summation orders are those of tti2d_kernel (kernels_tti.hip).
+// Sums run in the order of tti2d_kernel (kernels_tti.hip); the first-derivative weights carry 1 / h here, which that
+// kernel multiplies in afterwards (a rounding's difference).
 #include "mifwi_internal.hpp"
 
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__) && !defined(__gfx942__)
@@ -42,6 +43,10 @@ __device__ vf4 raw_buffer_load_f4(vi4 rsrc, int voffset, int soffset, int aux) _
 __device__ float raw_buffer_load_f1(vi4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.f32");
 __device__ int raw_buffer_load_i1(vi4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.i32");
 __device__ void raw_buffer_store_f4(vf4 v, vi4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.store.v4f32");
+// `size` bytes per lane from a buffer straight into LDS, lane i to lds + i * size (lds is wave-uniform); no registers
+// are held while the data is on its way
+__device__ void raw_buffer_load_lds(vi4 rsrc, __attribute__((address_space(3))) void *lds, int size, int voffset, int soffset,
+                                    int offset, int aux) __asm("llvm.amdgcn.raw.buffer.load.lds");
 namespace {
 __device__ inline vi4 tbuf_of(const void *p)
 {
@@ -102,9 +107,13 @@ __global__ __launch_bounds__(128, 2) void persist_tti2d_kernel(PersistTtiArgs q)
     __shared__ float zh[2][2][TX][P];              // cos * Gz outside the left / right edge: [field][side][row][column]
     __shared__ float xh_ct[2 * P * TQ][V], xh_st[2 * P * TQ][V];   // tilt at the points of the row tasks
     __shared__ float zt_ct[2 * TX][P], zt_st[2 * TX][P];           // and of the column tasks
-    __shared__ int s_own_off[4][NOWN];
-    __shared__ float s_own_w[4][NOWN];
-    __shared__ int s_list[NOWN];
+    constexpr int NOWN_T = GRAD ? 1 : NOWN;        // the gradient loop samples nothing
+    __shared__ int s_own_off[4][NOWN_T];
+    __shared__ float s_own_w[4][NOWN_T];
+    __shared__ int s_list[NOWN_T];
+    // gradient loop: the saved background levels of a step travel from memory straight into LDS (16 bytes per lane,
+    // a wave's lanes side by side) and wait there for the update at the end of the step
+    __shared__ __attribute__((aligned(16))) float ssave[GRAD ? 2 * H * NT * V : 4];
     __shared__ int s_misc[4];
 
     const Step2DArgs &a = q.a;
@@ -200,7 +209,7 @@ __global__ __launch_bounds__(128, 2) void persist_tti2d_kernel(PersistTtiArgs q)
     // sampled points whose first weighted corner lies in this tile: at most one per thread of the first NOWN
     // (forward loop: the staged image is sampled; backward loop: the levels themselves, which the image does not hold)
     int own_id = -1;
-    if (a.pt_idx) {
+    if (!GRAD && a.pt_idx) {
         const int tab = a.itp_per_shot ? shot : 0;
         for (int pnt = tid; pnt < a.itp_npoint; pnt += NT) {
             const int4 idx = *reinterpret_cast<const int4 *>(a.pt_idx + ((long)tab * a.itp_npoint + pnt) * 4);
@@ -298,6 +307,11 @@ __global__ __launch_bounds__(128, 2) void persist_tti2d_kernel(PersistTtiArgs q)
     const char *su_base = GRAD ? reinterpret_cast<const char *>(q.su + (long)shot * q.s_shot_stride) : nullptr;
     const char *sv_base = GRAD ? reinterpret_cast<const char *>(q.sv + (long)shot * q.s_shot_stride) : nullptr;
 
+    // first-derivative weights with 1 / h folded in (one rounding more per weight, two multiplications fewer per term)
+    float a1x[P + 1], a1z[P + 1];
+#pragma unroll
+    for (int j = 0; j <= P; ++j) a1x[j] = q.a1[j] * q.ihx, a1z[j] = q.a1[j] * q.ihz;
+
     int ctr[H];   // this thread's quads in the image (A; B is OFFB further)
 #pragma unroll
     for (int h = 0; h < H; ++h) ctr[h] = (tx + R) * PA + RZ + V * (tl + TL * h);
@@ -322,17 +336,20 @@ __global__ __launch_bounds__(128, 2) void persist_tti2d_kernel(PersistTtiArgs q)
 
         float wj = 0.f;
         if (fl & F_FEED) wj = a.winj[((long)shot * a.nt + time) * a.winj_stride + inj_base + tid];
-        // own points of the two stencilled fields: from registers
+        // own points of the two stencilled fields: from registers (backward loops: the combinations formed at the
+        // end of the previous step are in place already)
+        if (FWD || s == 0) {
 #pragma unroll
-        for (int h = 0; h < H; ++h) {
-            vf4 fa, fb;
+            for (int h = 0; h < H; ++h) {
+                vf4 fa, fb;
 #pragma unroll
-            for (int i = 0; i < V; ++i) {
-                fa[i] = FWD ? ucur[h][i] : et[h][i] * ucur[h][i] + dl[h][i] * vcur[h][i];
-                fb[i] = FWD ? vcur[h][i] : dl[h][i] * ucur[h][i] + vcur[h][i];
+                for (int i = 0; i < V; ++i) {
+                    fa[i] = FWD ? ucur[h][i] : et[h][i] * ucur[h][i] + dl[h][i] * vcur[h][i];
+                    fb[i] = FWD ? vcur[h][i] : dl[h][i] * ucur[h][i] + vcur[h][i];
+                }
+                *reinterpret_cast<vf4 *>(&sAB[ctr[h]]) = fa;
+                *reinterpret_cast<vf4 *>(&sAB[ctr[h] + OFFB]) = fb;
             }
-            *reinterpret_cast<vf4 *>(&sAB[ctr[h]]) = fa;
-            *reinterpret_cast<vf4 *>(&sAB[ctr[h] + OFFB]) = fb;
         }
         if (ninj > 0) {
 #pragma unroll
@@ -393,13 +410,15 @@ __global__ __launch_bounds__(128, 2) void persist_tti2d_kernel(PersistTtiArgs q)
             }
         __syncthreads();
         // saved background levels of this step: requested when the ring has arrived (see kernels_persist2d.hip)
-        vf4 su4[H], sv4[H];
+        if (GRAD) {
+            const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+            const vi4 suB = tbuf_of(su_base + (long)time * lvl_bytes), svB = tbuf_of(sv_base + (long)time * lvl_bytes);
 #pragma unroll
-        for (int h = 0; h < H; ++h) {
-            su4[h] = vf4{0.f, 0.f, 0.f, 0.f}, sv4[h] = vf4{0.f, 0.f, 0.f, 0.f};
-            if (GRAD) {
-                su4[h] = raw_buffer_load_f4(tbuf_of(su_base + (long)time * lvl_bytes), (int)pb[h], 0, kStream);
-                sv4[h] = raw_buffer_load_f4(tbuf_of(sv_base + (long)time * lvl_bytes), (int)pb[h], 0, kStream);
+            for (int h = 0; h < H; ++h) {
+                raw_buffer_load_lds(suB, (__attribute__((address_space(3))) void *)&ssave[((0 * H + h) * NT + wave * 64) * V], 16,
+                                    (int)pb[h], 0, 0, kStream);
+                raw_buffer_load_lds(svB, (__attribute__((address_space(3))) void *)&ssave[((1 * H + h) * NT + wave * 64) * V], 16,
+                                    (int)pb[h], 0, 0, kStream);
             }
         }
         if (FWD && (fl & F_OWN)) {
@@ -437,7 +456,7 @@ __global__ __launch_bounds__(128, 2) void persist_tti2d_kernel(PersistTtiArgs q)
 #pragma unroll
                 for (int j = 1; j <= P; ++j)
 #pragma unroll
-                    for (int i = 0; i < V; ++i) dz[i] += q.a1[j] * (la[RZ + i + j] - la[RZ + i - j]);
+                    for (int i = 0; i < V; ++i) dz[i] += a1z[j] * (la[RZ + i + j] - la[RZ + i - j]);
 #pragma unroll
                 for (int j = 1; j <= R; ++j) {
                     const vf4 lo = *reinterpret_cast<const vf4 *>(&sAB[ctr[h] - j * PA]);
@@ -446,13 +465,13 @@ __global__ __launch_bounds__(128, 2) void persist_tti2d_kernel(PersistTtiArgs q)
                     for (int i = 0; i < V; ++i) lap[h][i] += a.cx[j] * (lo[i] + hi[i]);
                     if (j <= P) {
 #pragma unroll
-                        for (int i = 0; i < V; ++i) dx[i] += q.a1[j] * (hi[i] - lo[i]);
+                        for (int i = 0; i < V; ++i) dx[i] += a1x[j] * (hi[i] - lo[i]);
                     }
                 }
                 vf4 sg4;
 #pragma unroll
                 for (int i = 0; i < V; ++i) {
-                    const float g = -(st[h][i] * (dx[i] * q.ihx) + ct[h][i] * (dz[i] * q.ihz));
+                    const float g = -(st[h][i] * dx[i] + ct[h][i] * dz[i]);
                     cgA[h][i] = ct[h][i] * g, sg4[i] = st[h][i] * g;
                 }
                 *reinterpret_cast<vf4 *>(&sgA[(tx + P) * PG + V * (tl + TL * h)]) = sg4;
@@ -482,14 +501,14 @@ __global__ __launch_bounds__(128, 2) void persist_tti2d_kernel(PersistTtiArgs q)
                     const vf4 hi = *reinterpret_cast<const vf4 *>(&sAB[ctr[h] + OFFB + j * PA]);
 #pragma unroll
                     for (int i = 0; i < V; ++i) {
-                        dx[i] += q.a1[j] * (hi[i] - lo[i]);
-                        dz[i] += q.a1[j] * (lb[P + i + j] - lb[P + i - j]);
+                        dx[i] += a1x[j] * (hi[i] - lo[i]);
+                        dz[i] += a1z[j] * (lb[P + i + j] - lb[P + i - j]);
                     }
                 }
                 vf4 sg4;
 #pragma unroll
                 for (int i = 0; i < V; ++i) {
-                    const float g = -(st[h][i] * (dx[i] * q.ihx) + ct[h][i] * (dz[i] * q.ihz));
+                    const float g = -(st[h][i] * dx[i] + ct[h][i] * dz[i]);
                     cgB[h][i] = ct[h][i] * g, sg4[i] = st[h][i] * g;
                 }
                 *reinterpret_cast<vf4 *>(&sgB[(tx + P) * PG + V * (tl + TL * h)]) = sg4;
@@ -507,14 +526,14 @@ __global__ __launch_bounds__(128, 2) void persist_tti2d_kernel(PersistTtiArgs q)
                 float dxa = 0.f, dza = 0.f, dxb = 0.f, dzb = 0.f;
 #pragma unroll
                 for (int j = 1; j <= P; ++j) {
-                    dxa += q.a1[j] * (sAB[c0i + i + j * PA] - sAB[c0i + i - j * PA]);
-                    dza += q.a1[j] * (sAB[c0i + i + j] - sAB[c0i + i - j]);
-                    dxb += q.a1[j] * (sAB[c0i + OFFB + i + j * PA] - sAB[c0i + OFFB + i - j * PA]);
-                    dzb += q.a1[j] * (sAB[c0i + OFFB + i + j] - sAB[c0i + OFFB + i - j]);
+                    dxa += a1x[j] * (sAB[c0i + i + j * PA] - sAB[c0i + i - j * PA]);
+                    dza += a1z[j] * (sAB[c0i + i + j] - sAB[c0i + i - j]);
+                    dxb += a1x[j] * (sAB[c0i + OFFB + i + j * PA] - sAB[c0i + OFFB + i - j * PA]);
+                    dzb += a1z[j] * (sAB[c0i + OFFB + i + j] - sAB[c0i + OFFB + i - j]);
                 }
                 const float cv = zt_ct[tid][i], sv = zt_st[tid][i];
-                const float ga = -(sv * (dxa * q.ihx) + cv * (dza * q.ihz));
-                const float gb = -(sv * (dxb * q.ihx) + cv * (dzb * q.ihz));
+                const float ga = -(sv * dxa + cv * dza);
+                const float gb = -(sv * dxb + cv * dzb);
                 zh[0][side][r][i] = cv * ga;
                 zh[1][side][r][i] = cv * gb;
             }
@@ -532,14 +551,14 @@ __global__ __launch_bounds__(128, 2) void persist_tti2d_kernel(PersistTtiArgs q)
                 float dxa = 0.f, dza = 0.f, dxb = 0.f, dzb = 0.f;
 #pragma unroll
                 for (int j = 1; j <= P; ++j) {
-                    dxa += q.a1[j] * (sAB[c0i + i + j * PA] - sAB[c0i + i - j * PA]);
-                    dza += q.a1[j] * (la[P + i + j] - la[P + i - j]);
-                    dxb += q.a1[j] * (sAB[c0i + OFFB + i + j * PA] - sAB[c0i + OFFB + i - j * PA]);
-                    dzb += q.a1[j] * (lb[P + i + j] - lb[P + i - j]);
+                    dxa += a1x[j] * (sAB[c0i + i + j * PA] - sAB[c0i + i - j * PA]);
+                    dza += a1z[j] * (la[P + i + j] - la[P + i - j]);
+                    dxb += a1x[j] * (sAB[c0i + OFFB + i + j * PA] - sAB[c0i + OFFB + i - j * PA]);
+                    dzb += a1z[j] * (lb[P + i + j] - lb[P + i - j]);
                 }
                 const float cv = xh_ct[t][i], sv = xh_st[t][i];
-                const float ga = -(sv * (dxa * q.ihx) + cv * (dza * q.ihz));
-                const float gb = -(sv * (dxb * q.ihx) + cv * (dzb * q.ihz));
+                const float ga = -(sv * dxa + cv * dza);
+                const float gb = -(sv * dxb + cv * dzb);
                 sa4[i] = sv * ga, sb4[i] = sv * gb;
             }
             *reinterpret_cast<vf4 *>(&sgA[er * PG + V * hq]) = sa4;
@@ -552,39 +571,46 @@ __global__ __launch_bounds__(128, 2) void persist_tti2d_kernel(PersistTtiArgs q)
         // l + 4 has the previous lane's second quad to its left (lane 0: quad 3 = lane 3's first quad) and the next
         // lane's second quad to its right (lane 3: outside the tile).  The two outside cases are filled in after the
         // barrier from what the column tasks left in LDS.
-        float eA[H][V + 2 * P], eB[H][V + 2 * P];
-#pragma unroll
-        for (int h = 0; h < H; ++h)
-#pragma unroll
-            for (int i = 0; i < V; ++i) eA[h][P + i] = cgA[h][i], eB[h][P + i] = cgB[h][i];
-#pragma unroll
-        for (int i = 0; i < P; ++i) {
-            float pa[H], pv[H], na[H], nv[H];   // previous lane: end of its quads; next lane: start of its quads
-#pragma unroll
-            for (int h = 0; h < H; ++h) {
-                pa[h] = quad_rotate<true>(cgA[h][V - P + i]), pv[h] = quad_rotate<true>(cgB[h][V - P + i]);
-                na[h] = quad_rotate<false>(cgA[h][i]), nv[h] = quad_rotate<false>(cgB[h][i]);
-            }
-            eA[0][i] = pa[0], eB[0][i] = pv[0];
-            eA[0][P + V + i] = (fl & F_RIGHT) ? na[1] : na[0], eB[0][P + V + i] = (fl & F_RIGHT) ? nv[1] : nv[0];
-            eA[1][i] = (fl & F_LEFT) ? pa[0] : pa[1], eB[1][i] = (fl & F_LEFT) ? pv[0] : pv[1];
-            eA[1][P + V + i] = na[1], eB[1][P + V + i] = nv[1];
-        }
         __syncthreads();
-        if (fl & F_LEFT) {
-#pragma unroll
-            for (int i = 0; i < P; ++i) eA[0][i] = zh[0][0][tx][i], eB[0][i] = zh[1][0][tx][i];
-        }
-        if (fl & F_RIGHT) {
-#pragma unroll
-            for (int i = 0; i < P; ++i) eA[1][P + V + i] = zh[0][1][tx][i], eB[1][P + V + i] = zh[1][1][tx][i];
-        }
+        // the saved levels are in LDS (vmcnt(0); waited for here, before this step's stores join the queue)
+        if (GRAD) __builtin_amdgcn_s_waitcnt(0x0f70);
 
         // ---- update of both fields -------------------------------------------------------------------------------------
         const bool ragged = (fl & F_RAGGED) != 0;   // a row of the grid ends inside one of this lane's quads (rare)
 #pragma unroll
         for (int h = 0; h < H; ++h) {
             __builtin_amdgcn_sched_barrier(0);
+            float eA[V + 2 * P], eB[V + 2 * P];   // the z line of cos * Gz through quad h
+#pragma unroll
+            for (int i = 0; i < V; ++i) eA[P + i] = cgA[h][i], eB[P + i] = cgB[h][i];
+#pragma unroll
+            for (int i = 0; i < P; ++i) {
+                // A row of the tile is four consecutive lanes, and the permutations are cyclic within them.  Left of
+                // quad l lies the previous lane's first quad (lane 0: outside the tile, filled in below); right of it
+                // the next lane's first quad, except for lane 3, where it is quad 4 = lane 0's second quad = the
+                // cyclically next lane's SECOND quad.  Left of quad l + 4 lies the previous lane's second quad, except
+                // for lane 0, where it is quad 3 = the cyclically previous lane's FIRST quad; right of it the next
+                // lane's second quad (lane 3: outside the tile).
+                if (h == 0) {
+                    eA[i] = quad_rotate<true>(cgA[0][V - P + i]), eB[i] = quad_rotate<true>(cgB[0][V - P + i]);
+                    const float na0 = quad_rotate<false>(cgA[0][i]), na1 = quad_rotate<false>(cgA[1][i]);
+                    const float nv0 = quad_rotate<false>(cgB[0][i]), nv1 = quad_rotate<false>(cgB[1][i]);
+                    eA[P + V + i] = (fl & F_RIGHT) ? na1 : na0, eB[P + V + i] = (fl & F_RIGHT) ? nv1 : nv0;
+                } else {
+                    const float pa0 = quad_rotate<true>(cgA[0][V - P + i]), pa1 = quad_rotate<true>(cgA[1][V - P + i]);
+                    const float pv0 = quad_rotate<true>(cgB[0][V - P + i]), pv1 = quad_rotate<true>(cgB[1][V - P + i]);
+                    eA[i] = (fl & F_LEFT) ? pa0 : pa1, eB[i] = (fl & F_LEFT) ? pv0 : pv1;
+                    eA[P + V + i] = quad_rotate<false>(cgA[1][i]), eB[P + V + i] = quad_rotate<false>(cgB[1][i]);
+                }
+            }
+            if (h == 0 && (fl & F_LEFT)) {
+#pragma unroll
+                for (int i = 0; i < P; ++i) eA[i] = zh[0][0][tx][i], eB[i] = zh[1][0][tx][i];
+            }
+            if (h == 1 && (fl & F_RIGHT)) {
+#pragma unroll
+                for (int i = 0; i < P; ++i) eA[P + V + i] = zh[0][1][tx][i], eB[P + V + i] = zh[1][1][tx][i];
+            }
             float un[V], vn[V];
             const int gq = (tx + P) * PG + V * (tl + TL * h);
             float sa[V], sb[V];
@@ -598,12 +624,10 @@ __global__ __launch_bounds__(128, 2) void persist_tti2d_kernel(PersistTtiArgs q)
                 const vf4 bhi = *reinterpret_cast<const vf4 *>(&sgB[gq + j * PG]);
 #pragma unroll
                 for (int i = 0; i < V; ++i) {
-                    float ta = q.a1[j] * (eA[h][P + i + j] - eA[h][P + i - j]) * q.ihz;
-                    ta += q.a1[j] * (ahi[i] - alo[i]) * q.ihx;
-                    sa[i] += ta;
-                    float tb = q.a1[j] * (eB[h][P + i + j] - eB[h][P + i - j]) * q.ihz;
-                    tb += q.a1[j] * (bhi[i] - blo[i]) * q.ihx;
-                    sb[i] += tb;
+                    sa[i] += a1z[j] * (eA[P + i + j] - eA[P + i - j]);
+                    sa[i] += a1x[j] * (ahi[i] - alo[i]);
+                    sb[i] += a1z[j] * (eB[P + i + j] - eB[P + i - j]);
+                    sb[i] += a1x[j] * (bhi[i] - blo[i]);
                 }
             }
 #pragma unroll
@@ -630,6 +654,12 @@ __global__ __launch_bounds__(128, 2) void persist_tti2d_kernel(PersistTtiArgs q)
             vf4 ca, cb;   // backward loops: the stencilled combinations of the new levels, for the neighbours
 #pragma unroll
             for (int i = 0; i < V; ++i) ca[i] = et[h][i] * un[i] + dl[h][i] * vn[i], cb[i] = dl[h][i] * un[i] + vn[i];
+            if (!FWD) {
+                // they are the next step's stencilled fields at this thread's points: nobody reads the image any more
+                // in this step (its last readers finished before the barrier above)
+                *reinterpret_cast<vf4 *>(&sAB[ctr[h]]) = ca;
+                *reinterpret_cast<vf4 *>(&sAB[ctr[h] + OFFB]) = cb;
+            }
             if (__builtin_expect(!ragged, 1)) {
                 raw_buffer_store_f4(vf4{un[0], un[1], un[2], un[3]}, rotuB, (int)pb[h], (int)out_off, kPlain);
                 raw_buffer_store_f4(vf4{vn[0], vn[1], vn[2], vn[3]}, rotvB, (int)pb[h], (int)out_off, kPlain);
@@ -653,11 +683,13 @@ __global__ __launch_bounds__(128, 2) void persist_tti2d_kernel(PersistTtiArgs q)
             }
             if (GRAD) {
                 // summed by parts over time (see tti2d_kernel): the second time difference is taken of the adjoint fields
+                const vf4 su4 = *reinterpret_cast<const vf4 *>(&ssave[((0 * H + h) * NT + tid) * V]);
+                const vf4 sv4 = *reinterpret_cast<const vf4 *>(&ssave[((1 * H + h) * NT + tid) * V]);
 #pragma unroll
                 for (int i = 0; i < V; ++i) {
                     const float ptt = (uold[h][i] - 2.0f * ucur[h][i] + un[i]) * a.inv_dt2;
                     const float rtt = (vold[h][i] - 2.0f * vcur[h][i] + vn[i]) * a.inv_dt2;
-                    gsum[h][i] += -(ptt * su4[h][i] + rtt * sv4[h][i]);
+                    gsum[h][i] += -(ptt * su4[i] + rtt * sv4[i]);
                 }
             }
 #pragma unroll
