@@ -1,11 +1,11 @@
 #!/usr/bin/env python
-"""Turn the rocprofv3 outputs of tools/profile_r2.sh into the summaries kept under profiles/:
+"""Turn the rocprofv3 outputs of tools/profile_bench_rocprof.sh into the summaries kept under profiles/:
   <out>_kernel_stats.txt  per (kernel, grid size): launches, mean / min / max duration from the kernel trace
   <out>_pmc.txt           per (kernel, grid size): mean FETCH_SIZE and WRITE_SIZE (KiB) per launch
   <out>_traffic.json      what bench.py reads: bytes and mean duration per launch of the benchmark's kernels
 Dispatches of one kernel are kept apart by grid size: the same step kernel runs with interpolation blocks in the
 forward loops and without them in the gradient loops, and the 4- and 32-shot legs of the bench use other grids.
-Usage: profile_r2_summary.py <dir with trace/ p1/ p2/> <output prefix>"""
+Usage: profile_bench_summary.py <dir with trace/ p1/ p2/> <output prefix>"""
 import csv, glob, json, os, sys
 from collections import defaultdict
 
@@ -22,7 +22,7 @@ for f in glob.glob(os.path.join(src, "trace", "**", "*kernel_trace.csv"), recurs
     for row in csv.DictReader(open(f)):
         dur[(short(row["Kernel_Name"]), int(row["Grid_Size_X"]) * int(row["Grid_Size_Y"]) * int(row["Grid_Size_Z"]))].append((int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) / 1e3)
 with open(out + "_kernel_stats.txt", "w") as fo:
-    fo.write("# rocprofv3 --kernel-trace of: python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-batches\n")
+    fo.write("# rocprofv3 --kernel-trace of: python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-batches --no-strong\n")
     fo.write("# durations in microseconds, per (kernel, grid size in threads)\n")
     fo.write("%-62s %10s %8s %12s %10s %10s %10s\n" % ("kernel", "grid", "calls", "total_us", "avg_us", "min_us", "max_us"))
     for (k, g), v in sorted(dur.items(), key=lambda kv: -sum(kv[1])):
@@ -65,7 +65,7 @@ def entry(parts):
 
 # grids of the benchmark: 8 shots x 98 tiles of 32 x 32 (+ 16 interpolation blocks in forward loops), 256 threads;
 # 592^3: 370 tiles x 6 chunks (+ 16 interpolation blocks) forward, 370 x 4 chunks in the gradient loop
-traffic = {"_comment": "Per launch, from rocprofv3 of `python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-batches`: mean "
+traffic = {"_comment": "Per launch, from rocprofv3 of `python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-batches --no-strong`: mean "
                        "duration from the kernel trace, fabric-side bytes = 2 x FETCH_SIZE + WRITE_SIZE (FETCH_SIZE "
                        "tallies 128-byte requests at 64 bytes on gfx950). For the 2-D kernels the working set lives in "
                        "the 256 MB last-level cache: these are bytes leaving the L2s, an upper bound on HBM traffic. "
@@ -84,6 +84,12 @@ for name, parts in spec.items():
 # whole-loop launches of the 2-D time loops (one launch = nt - 2 steps of 8 shots): every grid of the kernel
 for name, frag in (("persist2d_kernel", "persist2d_kernel<8, 32, 32, 0,"), ("persist2d_kernel<GRAD>", "persist2d_kernel<8, 32, 32, 1,")):
     parts = [(k[0], k[1]) for k in dur if frag in k[0]]
+    e = entry(parts) if parts else None
+    if e:
+        traffic[name] = e
+# whole-loop launches of the 2-D TTI time loops (template arguments: radius, variant 0 forward / 1 adjoint / 2 gradient)
+for mode, name in ((0, "persist_tti2d_kernel"), (1, "persist_tti2d_kernel<ADJ>"), (2, "persist_tti2d_kernel<GRAD>")):
+    parts = [(k[0], k[1]) for k in dur if k[0].startswith("persist_tti2d_kernel<") and k[0].rstrip().endswith(", %d>" % mode)]
     e = entry(parts) if parts else None
     if e:
         traffic[name] = e
