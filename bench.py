@@ -43,7 +43,7 @@ SHOTS_PER_GPU = 8
 
 def pmc_traffic(kernel):
     """HBM-side bytes per launch of `kernel` from the committed rocprofv3 PMC passes of this same
-    command (profiles/r2_traffic.json), or None when no such measurement is recorded."""
+    command (the newest profiles/r*_traffic.json), or None when no such measurement is recorded."""
     return _profile_entry(kernel).get("bytes")
 
 
@@ -62,7 +62,7 @@ def _profile_entry(kernel):
 
 def exchange_floor_us():
     """Cost of one step of the whole-loop kernel's neighbour exchange alone (counters, halo ring from the XCD's L2,
-    tile store, acknowledgement; no stencil, no saved level), measured by tools/micro/xcdsync.hip on this part and
+    tile store, acknowledgement; no stencil, no saved level), measured by tools/micro/xcdsplit.hip on this part and
     recorded in profiles/: the bound of that kernel."""
     for name in ("r3_exchange_floor.json", "r2_exchange_floor.json"):
         try:
@@ -597,8 +597,9 @@ def main():
                 "profile_avg_launch_us": prof_us,
                 "profile_frac": (g_bytes_loop / max(1, bwd_launches)) / (prof_us * 1e-6) / 1e9 / HBM_PEAK_GBS
                 if prof_us else None,
-                "profile": "profiles/r2_05_bench_kernel_stats.txt: rocprofv3 --kernel-trace of this command with --no-batches, mean over "
-                           "the backward loop's launches (plain and two-step gradient launches weighted by count)",
+                "profile": "%s: rocprofv3 --kernel-trace of this command with --no-batches, mean over the backward loop's "
+                           "launches (plain and two-step gradient launches weighted by count)" %
+                           _profile_entry(st["bwd_kernel"]).get("source"),
                 "profile_note": "the tracer slows these ~5 us launches: HIP events around the same loop read 8.7 us "
                                 "per launch under rocprofv3 and 5.6 us without it (profiles/r2_01_bench_line_under_trace.json "
                                 "vs profiles/r2_01_bench_line_untraced.json), so the traced kernel-only mean exceeds the "
