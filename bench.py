@@ -269,39 +269,56 @@ def c4_leg(mifwi, device, space_order=8, n=512, nbl=40, nt=500):
     g = np.linspace(0, (n - 1) * 10.0, 64, dtype=np.float32)
     rec = np.stack(np.meshgrid(g, g, indexing="ij"), -1).reshape(-1, 2)
     rec = np.concatenate([rec, np.full((rec.shape[0], 1), 20.0, np.float32)], 1)
-    plan = mifwi.Plan(sp, model.spacing, model.grid.origin, space_order, nt, dt, 1, rec.shape[0], max_shots=1,
-                      device=device)
-    plan.set_geometry(src, rec)
     t = np.arange(nt) * dt
     r = np.pi * 0.010 * (t - 100.0)
     dev = torch.device("cuda", device)
     wav = torch.from_numpy(((1 - 2 * r ** 2) * np.exp(-r ** 2)).astype(np.float32).reshape(nt, 1)).to(dev)
     obs = torch.empty((1, nt, rec.shape[0]), dtype=torch.float32, device=dev)
-    grad = torch.empty((1,) + sp, dtype=torch.float32, device=dev)
     fval = torch.zeros(1, dtype=torch.float64, device=dev)
-    plan.set_model(model.vp.data, model.damp.data)
-    plan.forward(wav, rec_out=obs)
-    plan.set_model(model0.vp.data, model0.damp.data)
-    walls = []
-    for _ in range(2):
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        plan.l2_misfit_gradient(wav, obs, grad=grad, fval=fval, want_illum=False)
-        torch.cuda.synchronize()
-        walls.append(time.perf_counter() - t0)
-    st = plan.stats()
-    objective = float(fval.item())
-    plan.close()
-    del grad, obs
-    torch.cuda.empty_cache()
     pts = 2.0 * (nt - 2) * float(np.prod(sp))
-    return {"workload": "synthetic 3-D %d^3 (+nbl %d = %d^3), space_order=%d, nt=%d, 1 shot: forward + L2 gradient; "
-                        "the first %d steps checkpointed in segments of %d and propagated twice, the levels of the "
-                        "other %d stored" % (n, nbl, sp[0], space_order, nt, st["ckpt_steps"], st["ckpt_segment"],
-                                             nt - 2 - st["ckpt_steps"]),
-            "gpoints_per_s": pts / walls[1] / 1e9, "wall_ms": walls[1] * 1e3, "first_call_wall_ms": walls[0] * 1e3,
-            "forward_loop_ms": st["fwd_ms"], "gradient_loop_ms_incl_recomputation": st["bwd_ms"],
-            "checkpointed_steps": st["ckpt_steps"], "device_bytes": st["device_bytes"], "objective": objective}
+    out, grad_f32 = None, None
+    # the float32 default first; then the same evaluation with the saved levels in half precision
+    # (MIFWI_FLAG_SAVE_F16: every level fits, nothing is propagated twice; the gradient differs in the 5th digit)
+    for flags in (0, mifwi.FLAG_SAVE_F16):
+        plan = mifwi.Plan(sp, model.spacing, model.grid.origin, space_order, nt, dt, 1, rec.shape[0], max_shots=1,
+                          device=device, flags=flags)
+        plan.set_geometry(src, rec)
+        if flags == 0:
+            plan.set_model(model.vp.data, model.damp.data)
+            plan.forward(wav, rec_out=obs)
+        plan.set_model(model0.vp.data, model0.damp.data)
+        grad = torch.empty((1,) + sp, dtype=torch.float32, device=dev)
+        walls = []
+        for _ in range(2):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            plan.l2_misfit_gradient(wav, obs, grad=grad, fval=fval, want_illum=False)
+            torch.cuda.synchronize()
+            walls.append(time.perf_counter() - t0)
+        st = plan.stats()
+        objective = float(fval.item())
+        plan.close()
+        leg = {"gpoints_per_s": pts / walls[1] / 1e9, "wall_ms": walls[1] * 1e3, "first_call_wall_ms": walls[0] * 1e3,
+               "forward_loop_ms": st["fwd_ms"], "gradient_loop_ms_incl_recomputation": st["bwd_ms"],
+               "checkpointed_steps": st["ckpt_steps"], "device_bytes": st["device_bytes"], "objective": objective}
+        if flags == 0:
+            out = dict({"workload": "synthetic 3-D %d^3 (+nbl %d = %d^3), space_order=%d, nt=%d, 1 shot: forward + L2 "
+                                    "gradient; the first %d steps checkpointed in segments of %d and propagated twice, "
+                                    "the levels of the other %d stored" %
+                                    (n, nbl, sp[0], space_order, nt, st["ckpt_steps"], st["ckpt_segment"],
+                                     nt - 2 - st["ckpt_steps"])}, **leg)
+            grad_f32 = grad
+        else:
+            num = float(torch.linalg.vector_norm((grad - grad_f32).double()))
+            den = float(torch.linalg.vector_norm(grad_f32.double()))
+            leg["gradient_rel_l2_vs_float32_levels"] = num / den
+            leg["what"] = "same evaluation with MIFWI_FLAG_SAVE_F16 (opt-in): saved levels in half precision, all stored"
+            out["saved_levels_f16"] = leg
+        del grad
+        torch.cuda.empty_cache()
+    del grad_f32, obs
+    torch.cuda.empty_cache()
+    return out
 
 
 def fwi_iteration(true_model, init_model, src_all, rec, k=3, reps=3):
