@@ -2053,7 +2053,10 @@ static int enqueue_persist_tti(Plan &p, int nshots, int mode, float *fu, float *
         if (s0 > 0) MIFWI_HIP(hipMemsetAsync(p.d_psync, 0, ngroup_words * sizeof(int), p.stream));
         q.a.shot0 = s0;
         q.a.nshots = std::min(8, nshots - s0);
-        if ((rc = launch_persist_tti2d(p, q, mode, std::min(resident, ntiles + 16), p.stream))) return rc;
+        // blocks beyond the tiles leave at once; tests raise their number so that the tiles of a small grid share CUs
+        int surplus = 16;
+        if (const char *env = getenv("MIFWI_TTI_SURPLUS_BLOCKS")) surplus = std::max(0, atoi(env));
+        if ((rc = launch_persist_tti2d(p, q, mode, std::min(resident, ntiles + surplus), p.stream))) return rc;
         if (p.persist_check && (rc = launch_persist2d_check(q.done, q.a.nshots * ntiles, q.nsteps, q.abort_flag, p.stream))) return rc;
         launches += 1;
     }

@@ -106,8 +106,8 @@ def test_3d_512_gradient_checkpoint_identity_and_jacobian_pair(mifwi):
     r = rng.standard_normal((1, nt, nrec)).astype(np.float32)
     dev = torch.device("cuda")
     grads = {}
-    # "full" runs each loop of these 8 shots as one launch, "steps" and "ckpt" a kernel per step
-    for name, flags in (("full", 0), ("steps", mifwi.FLAG_NO_GRAPH), ("ckpt", mifwi.FLAG_CHECKPOINT)):
+    # 3-D loops run a kernel per step either way: the fully saved and the checkpointed plan share the schedule
+    for name, flags in (("full", 0), ("ckpt", mifwi.FLAG_CHECKPOINT)):
         plan = mifwi.Plan(sp, model.spacing, model.grid.origin, so, nt, dt, 1, nrec, max_shots=1, flags=flags)
         plan.set_model(model.vp.data, model.damp.data)
         plan.set_geometry(src, rec)
@@ -205,6 +205,11 @@ def test_marmousi2_tti_full_size_pairs(mifwi):
     fs = plan.tti_forward(s, wavelet_per_shot=True)
     ftr = plan.tti_adjoint(r)
     assert np.isfinite(fs).all() and np.abs(fs).max() > 0
+    # 98 tiles per shot: three to four share a CU.  The loops must repeat bit for bit (they did not while the kernel
+    # overwrote the data registers of its 16-byte stores too early, tests/test_gpu_tti_whole_loop.py)
+    assert plan.stats()["bwd_kernel"].startswith("persist_tti2d_kernel")
+    assert np.array_equal(fs, plan.tti_forward(s, wavelet_per_shot=True))
+    assert np.array_equal(ftr, plan.tti_adjoint(r))
     for k in range(nshots):
         assert _pair_ok(fs[k], r[k], s[k], ftr[k], 3e-6), k
     dm = np.zeros(model.grid.shape, np.float32)

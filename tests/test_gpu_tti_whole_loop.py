@@ -121,3 +121,21 @@ def test_space_orders_without_a_whole_loop_kernel_keep_the_kernel_per_step(mifwi
     res = rng.standard_normal((2, nt, rec.shape[0])).astype(np.float32)
     got = _run(mifwi, prob, dt, nt, src, rec, w, res, 0)
     assert got["fwd_kernel"] == "step2d_kernel" and got["fallbacks"] == 0
+
+
+def test_whole_loop_tti_repeats_bit_for_bit_when_tiles_share_a_cu(mifwi, monkeypatch):
+    """Run-to-run identity with several resident tiles per CU.  The first version of the kernel overwrote the data
+    registers of its 16-byte stores in the next issue slot; on gfx950 that reaches the store when another wave keeps
+    the SIMD busy, so results differed from run to run as soon as two tiles shared a CU (any grid of more than 16
+    tiles, i.e. the Marmousi-II benchmark), while every small test grid passed.  Surplus blocks (they leave at once)
+    make the 16 tiles of this grid share CUs; without them every tile has a CU of its own."""
+    prob, dt, nt, src, rec, w, rng = _setup((120, 120), 8, 1, 1, nt=200)
+    res = rng.standard_normal((1, nt, rec.shape[0])).astype(np.float32)
+    monkeypatch.setenv("MIFWI_TTI_SURPLUS_BLOCKS", "0")
+    alone = _run(mifwi, prob, dt, nt, src, rec, w, res, 0)
+    monkeypatch.setenv("MIFWI_TTI_SURPLUS_BLOCKS", "100")
+    for _ in range(4):
+        shared = _run(mifwi, prob, dt, nt, src, rec, w, res, 0)
+        assert shared["fwd_kernel"] == "persist_tti2d_kernel" and shared["fallbacks"] == 0
+        for key in ("d0", "d1", "u3", "a", "r6", "u_saved", "g"):
+            assert np.array_equal(alone[key], shared[key]), key
