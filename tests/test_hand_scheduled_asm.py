@@ -16,14 +16,32 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 
 
-@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not available")
-def test_no_instruction_touches_a_register_with_a_load_in_flight(tmp_path):
-    import check_pending_regs
+KERNEL_FILES = ["kernels_generic", "kernels_tiled2d", "kernels_persist2d", "kernels_persist_tti2d", "kernels_3d", "kernels_tti"]
+
+
+@pytest.fixture(scope="module")
+def assembly(tmp_path_factory):
+    """gfx950 assembly of every kernel file, compiled side by side (device code only)."""
+    if not os.path.exists(HIPCC):
+        pytest.skip("hipcc not available")
+    out = tmp_path_factory.mktemp("asm")
     csrc = os.path.join(ROOT, "devito-fwi_amd", "csrc")
     flags = subprocess.check_output(["make", "-s", "-C", csrc, "print-cxxflags"], text=True).split()
-    asm = str(tmp_path / "kernels_tti.s")
-    subprocess.check_call([HIPCC] + flags + ["--cuda-device-only", "-S", os.path.join(csrc, "kernels_tti.hip"), "-o", asm],
-                          cwd=csrc, stderr=subprocess.DEVNULL)
+    jobs = {}
+    for name in KERNEL_FILES:
+        asm = str(out / (name + ".s"))
+        jobs[name] = (asm, subprocess.Popen([HIPCC] + flags + ["--cuda-device-only", "-S", os.path.join(csrc, name + ".hip"),
+                                                               "-o", asm], cwd=csrc, stderr=subprocess.DEVNULL))
+    paths = {}
+    for name, (asm, proc) in jobs.items():
+        assert proc.wait() == 0, name
+        paths[name] = asm
+    return paths
+
+
+def test_no_instruction_touches_a_register_with_a_load_in_flight(assembly):
+    import check_pending_regs
+    asm = assembly["kernels_tti"]
     KERNELS = ["tti3d_fused_kernel", "tti3d_step_kernel", "tti3d_step_wide_kernel", "tti3d_gz_kernel"]
     bad, nfun = check_pending_regs.check_file(asm, KERNELS)
     assert nfun == 10     # radius 2, 4 of the single march; 2, 4 and 6, 8 (wide) of the step, p = 1 .. 4 of the Gz march
@@ -33,23 +51,15 @@ def test_no_instruction_touches_a_register_with_a_load_in_flight(tmp_path):
     assert check_pending_regs.scratch_ops(asm, KERNELS) == 0
 
 
-KERNEL_FILES = ["kernels_generic", "kernels_tiled2d", "kernels_persist2d", "kernels_persist_tti2d", "kernels_3d", "kernels_tti"]
-
-
-@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not available")
 @pytest.mark.parametrize("name", KERNEL_FILES)
-def test_data_registers_of_wide_stores_are_left_alone(tmp_path, name):
+def test_data_registers_of_wide_stores_are_left_alone(assembly, name):
     """A vector instruction that overwrites a data register of a 16-byte store in the issue slots right behind it can
     reach the store on gfx950 (run-to-run different results in the whole-loop TTI kernel once two tiles shared a CU;
     the compiler guards the constant-offset form only).  Every kernel of the library must leave such registers alone
     for at least 4 wait states (twice what the compiler inserts for the form it does guard); the kernel where the
     compiler left none is kernels_persist_tti2d.hip, whose stores go through store_f4_held (8 wait states)."""
     import check_store_data_hold
-    csrc = os.path.join(ROOT, "devito-fwi_amd", "csrc")
-    flags = subprocess.check_output(["make", "-s", "-C", csrc, "print-cxxflags"], text=True).split()
-    asm = str(tmp_path / (name + ".s"))
-    subprocess.check_call([HIPCC] + flags + ["--cuda-device-only", "-S", os.path.join(csrc, name + ".hip"), "-o", asm],
-                          cwd=csrc, stderr=subprocess.DEVNULL)
+    asm = assembly[name]
     found = check_store_data_hold.check_file(asm, 4)
     assert not found, found[:4]
 
