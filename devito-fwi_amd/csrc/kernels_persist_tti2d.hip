@@ -4,7 +4,9 @@
 //
 // Every tile of a shot keeps a 128-thread block resident for the whole loop; a thread owns two quads of four consecutive
 // z points of one row (quads l and l + 4 of the row's eight: a wave's 16-byte LDS reads are then conflict free with a
-// row pitch of 80 floats, which is exactly the two fields' rows side by side).  Two waves per tile leave 256 registers
+// row pitch of 80 floats, which is exactly the two fields' rows side by side).  Every per-point value of a thread is a
+// pair {quad l, quad l + 4}: written that way all the arithmetic compiles to packed two-float instructions with one
+// coefficient each (packing along z would need operands shifted by an odd number of points).  Two waves per tile leave 256 registers
 // to a thread at the four tiles per CU that a Marmousi-sized shot needs on its XCD: the state of eight points of two
 // fields does not fit 128.  m, eta dt, 1 + 2 eps, sqrt(1 + 2 delta), cos and sin of the tilt and the two newest levels of both fields at
 // those points stay in registers; per step a block reads only the halo ring of the two fields' newest level (written
@@ -297,25 +299,30 @@ __global__ __launch_bounds__(128, 2) void persist_tti2d_kernel(PersistTtiArgs q)
         }
     }
 
-    // state kept in registers for the whole loop
+    // State kept in registers for the whole loop.  The thread's two quads are the two components of a pair: every
+    // per-point value is a vf2 {quad l, quad l + 4}, so that one packed instruction (v_pk_fma_f32 and friends) serves
+    // both quads with the same coefficient -- no operand has to be shifted by an odd number of points, which is what
+    // keeps the compiler from packing along z.
     const int time0 = q.forward ? 1 : a.nt - 2;
     const int dir = q.forward ? 1 : -1;
-    float mm[H][V], ed[H][V], et[H][V], dl[H][V], ct[H][V], st[H][V], ucur[H][V], uold[H][V], vcur[H][V], vold[H][V], gsum[H][V];
+    vf2 mm[V], ed[V], et[V], dl[V], ct[V], st[V], ucur[V], uold[V], vcur[V], vold[V], gsum[V];
 #pragma unroll
-    for (int h = 0; h < H; ++h)
+    for (int i = 0; i < V; ++i) {
+        mm[i] = vf2{1.f, 1.f}, ed[i] = vf2{0.f, 0.f}, et[i] = vf2{1.f, 1.f}, dl[i] = vf2{1.f, 1.f}, ct[i] = vf2{1.f, 1.f};
+        st[i] = vf2{0.f, 0.f}, ucur[i] = vf2{0.f, 0.f}, uold[i] = vf2{0.f, 0.f}, vcur[i] = vf2{0.f, 0.f}, vold[i] = vf2{0.f, 0.f};
+        gsum[i] = vf2{0.f, 0.f};
 #pragma unroll
-        for (int i = 0; i < V; ++i) {
-            mm[h][i] = 1.f, ed[h][i] = 0.f, et[h][i] = 1.f, dl[h][i] = 1.f, ct[h][i] = 1.f, st[h][i] = 0.f;
-            ucur[h][i] = 0.f, uold[h][i] = 0.f, vcur[h][i] = 0.f, vold[h][i] = 0.f, gsum[h][i] = 0.f;
+        for (int h = 0; h < H; ++h)
             if (x < a.n1 && zq[h] + i < a.n2) {   // (set-up only)
                 const long e = at(x, zq[h] + i);
-                mm[h][i] = a.m[e], ed[h][i] = a.eta[e] * a.dt, et[h][i] = q.et[e], dl[h][i] = q.dl[e], ct[h][i] = q.ct[e],
-                st[h][i] = q.st[e];
+                mm[i][h] = a.m[e], ed[i][h] = a.eta[e] * a.dt, et[i][h] = q.et[e], dl[i][h] = q.dl[e], ct[i][h] = q.ct[e];
+                st[i][h] = q.st[e];
                 const long c = (long)(time0 % 3) * q.field + e, o = (long)((time0 - dir + 3) % 3) * q.field + e;
-                ucur[h][i] = rotu[c], uold[h][i] = rotu[o], vcur[h][i] = rotv[c], vold[h][i] = rotv[o];
-                if (GRAD) gsum[h][i] = q.grad[(long)shot * q.g_shot_stride + e];
+                ucur[i][h] = rotu[c], uold[i][h] = rotu[o], vcur[i][h] = rotv[c], vold[i][h] = rotv[o];
+                if (GRAD) gsum[i][h] = q.grad[(long)shot * q.g_shot_stride + e];
             }
-        }
+    }
+    const vf2 dt2p = vf2{dt2l[0], dt2l[1]};
     const char *su_base = GRAD ? reinterpret_cast<const char *>(q.su + (long)shot * q.s_shot_stride) : nullptr;
     const char *sv_base = GRAD ? reinterpret_cast<const char *>(q.sv + (long)shot * q.s_shot_stride) : nullptr;
 
@@ -327,6 +334,16 @@ __global__ __launch_bounds__(128, 2) void persist_tti2d_kernel(PersistTtiArgs q)
     int ctr[H];   // this thread's quads in the image (A; B is OFFB further)
 #pragma unroll
     for (int h = 0; h < H; ++h) ctr[h] = (tx + R) * PA + RZ + V * (tl + TL * h);
+    // a quad of each of the thread's two: 16-byte LDS reads at the two places, combined point by point
+    auto ld2 = [&](const float *base, int o0, int o1, vf2 *out) {
+        const vf4 x0 = *reinterpret_cast<const vf4 *>(base + o0), x1 = *reinterpret_cast<const vf4 *>(base + o1);
+#pragma unroll
+        for (int i = 0; i < V; ++i) out[i] = vf2{x0[i], x1[i]};
+    };
+    auto st2 = [&](float *base, int o0, int o1, const vf2 *in) {
+        *reinterpret_cast<vf4 *>(base + o0) = vf4{in[0][0], in[1][0], in[2][0], in[3][0]};
+        *reinterpret_cast<vf4 *>(base + o1) = vf4{in[0][1], in[1][1], in[2][1], in[3][1]};
+    };
     __syncthreads();   // the task tables are complete
 
     for (int s = 0; s < q.nsteps; ++s) {
@@ -342,26 +359,21 @@ __global__ __launch_bounds__(128, 2) void persist_tti2d_kernel(PersistTtiArgs q)
         int fl = flags;
         asm volatile("" : "+v"(fl));
 #pragma unroll
-        for (int h = 0; h < H; ++h)
-#pragma unroll
-            for (int i = 0; i < V; ++i) asm volatile("" : "+v"(mm[h][i]), "+v"(ed[h][i]));
+        for (int i = 0; i < V; ++i) asm volatile("" : "+v"(mm[i]), "+v"(ed[i]));
 
         float wj = 0.f;
         if (fl & F_FEED) wj = a.winj[((long)shot * a.nt + time) * a.winj_stride + inj_base + tid];
         // own points of the two stencilled fields: from registers (backward loops: the combinations formed at the
         // end of the previous step are in place already)
         if (FWD || s == 0) {
+            vf2 fa[V], fb[V];
 #pragma unroll
-            for (int h = 0; h < H; ++h) {
-                vf4 fa, fb;
-#pragma unroll
-                for (int i = 0; i < V; ++i) {
-                    fa[i] = FWD ? ucur[h][i] : et[h][i] * ucur[h][i] + dl[h][i] * vcur[h][i];
-                    fb[i] = FWD ? vcur[h][i] : dl[h][i] * ucur[h][i] + vcur[h][i];
-                }
-                *reinterpret_cast<vf4 *>(&sAB[ctr[h]]) = fa;
-                *reinterpret_cast<vf4 *>(&sAB[ctr[h] + OFFB]) = fb;
+            for (int i = 0; i < V; ++i) {
+                fa[i] = FWD ? ucur[i] : et[i] * ucur[i] + dl[i] * vcur[i];
+                fb[i] = FWD ? vcur[i] : dl[i] * ucur[i] + vcur[i];
             }
+            st2(sAB, ctr[0], ctr[1], fa);
+            st2(sAB, ctr[0] + OFFB, ctr[1] + OFFB, fb);
         }
         if (ninj > 0) {
 #pragma unroll
@@ -444,89 +456,84 @@ __global__ __launch_bounds__(128, 2) void persist_tti2d_kernel(PersistTtiArgs q)
         }
 
         // ---- Gz of both fields at this thread's points; Laplacian of A -----------------------------------------
-        float lap[H][V], cgA[H][V], cgB[H][V];
+        vf2 lap[V], cgA[V], cgB[V];
+        __builtin_amdgcn_sched_barrier(0);   // one field at a time: the phases are long enough as they are
+        {
+            // field A: its line of 12 values serves the z part of the Laplacian and the z derivative, the rows above
+            // and below the x parts
+            vf2 la[V + 2 * RZ];
 #pragma unroll
-        for (int h = 0; h < H; ++h) {
-            __builtin_amdgcn_sched_barrier(0);   // one quad and one field at a time: the phases are long enough as they are
+            for (int k = 0; k < (V + 2 * RZ) / V; ++k) ld2(sAB, ctr[0] - RZ + V * k, ctr[1] - RZ + V * k, &la[V * k]);
+            vf2 dx[V], dz[V];
+#pragma unroll
+            for (int i = 0; i < V; ++i) lap[i] = a.c0 * la[RZ + i], dx[i] = vf2{0.f, 0.f}, dz[i] = vf2{0.f, 0.f};
+#pragma unroll
+            for (int j = 1; j <= R; ++j)
+#pragma unroll
+                for (int i = 0; i < V; ++i) lap[i] += a.cz[j] * (la[RZ + i - j] + la[RZ + i + j]);
+#pragma unroll
+            for (int j = 1; j <= P; ++j)
+#pragma unroll
+                for (int i = 0; i < V; ++i) dz[i] += a1z[j] * (la[RZ + i + j] - la[RZ + i - j]);
+#pragma unroll
+            for (int j = 1; j <= R; ++j) {
+                vf2 lo[V], hi[V];
+                ld2(sAB, ctr[0] - j * PA, ctr[1] - j * PA, lo);
+                ld2(sAB, ctr[0] + j * PA, ctr[1] + j * PA, hi);
+#pragma unroll
+                for (int i = 0; i < V; ++i) lap[i] += a.cx[j] * (lo[i] + hi[i]);
+                if (j <= P) {
+#pragma unroll
+                    for (int i = 0; i < V; ++i) dx[i] += a1x[j] * (hi[i] - lo[i]);
+                }
+            }
+            vf2 sg[V];
+#pragma unroll
+            for (int i = 0; i < V; ++i) {
+                const vf2 g = -(st[i] * dx[i] + ct[i] * dz[i]);
+                cgA[i] = ct[i] * g, sg[i] = st[i] * g;
+            }
+            st2(sgA, (tx + P) * PG + V * tl, (tx + P) * PG + V * (tl + TL), sg);
+            // the sums are complete HERE: left to itself the compiler moves them down to their use in the update and
+            // keeps the quads they are formed from alive until then (registers spilled)
+#pragma unroll
+            for (int i = 0; i < V; ++i) asm volatile("" : "+v"(lap[i]), "+v"(cgA[i]));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        {
+            vf2 lb[V + 2 * P];   // z - P .. z + 3 + P
             {
-                // field A: its line of 12 values serves the z part of the Laplacian and the z derivative, the rows above
-                // and below the x parts
-                float la[V + 2 * RZ];
+                const vf2 l0 = *reinterpret_cast<const vf2 *>(&sAB[ctr[0] + OFFB - 2]), l1 = *reinterpret_cast<const vf2 *>(&sAB[ctr[1] + OFFB - 2]);
+                const vf2 r0 = *reinterpret_cast<const vf2 *>(&sAB[ctr[0] + OFFB + V]), r1 = *reinterpret_cast<const vf2 *>(&sAB[ctr[1] + OFFB + V]);
+                if (P == 2)
+                    lb[0] = vf2{l0[0], l1[0]}, lb[1] = vf2{l0[1], l1[1]}, lb[V + 2] = vf2{r0[0], r1[0]}, lb[V + 3] = vf2{r0[1], r1[1]};
+                else
+                    lb[0] = vf2{l0[1], l1[1]}, lb[V + 1] = vf2{r0[0], r1[0]};
+                ld2(sAB, ctr[0] + OFFB, ctr[1] + OFFB, &lb[P]);
+            }
+            vf2 dx[V], dz[V];
 #pragma unroll
-                for (int k = 0; k < (V + 2 * RZ) / V; ++k) {
-                    const vf4 ta = *reinterpret_cast<const vf4 *>(&sAB[ctr[h] - RZ + V * k]);
+            for (int i = 0; i < V; ++i) dx[i] = vf2{0.f, 0.f}, dz[i] = vf2{0.f, 0.f};
 #pragma unroll
-                    for (int i = 0; i < V; ++i) la[V * k + i] = ta[i];
-                }
-                float dx[V], dz[V];
-#pragma unroll
-                for (int i = 0; i < V; ++i) lap[h][i] = a.c0 * la[RZ + i], dx[i] = 0.f, dz[i] = 0.f;
-#pragma unroll
-                for (int j = 1; j <= R; ++j)
-#pragma unroll
-                    for (int i = 0; i < V; ++i) lap[h][i] += a.cz[j] * (la[RZ + i - j] + la[RZ + i + j]);
-#pragma unroll
-                for (int j = 1; j <= P; ++j)
-#pragma unroll
-                    for (int i = 0; i < V; ++i) dz[i] += a1z[j] * (la[RZ + i + j] - la[RZ + i - j]);
-#pragma unroll
-                for (int j = 1; j <= R; ++j) {
-                    const vf4 lo = *reinterpret_cast<const vf4 *>(&sAB[ctr[h] - j * PA]);
-                    const vf4 hi = *reinterpret_cast<const vf4 *>(&sAB[ctr[h] + j * PA]);
-#pragma unroll
-                    for (int i = 0; i < V; ++i) lap[h][i] += a.cx[j] * (lo[i] + hi[i]);
-                    if (j <= P) {
-#pragma unroll
-                        for (int i = 0; i < V; ++i) dx[i] += a1x[j] * (hi[i] - lo[i]);
-                    }
-                }
-                vf4 sg4;
+            for (int j = 1; j <= P; ++j) {
+                vf2 lo[V], hi[V];
+                ld2(sAB, ctr[0] + OFFB - j * PA, ctr[1] + OFFB - j * PA, lo);
+                ld2(sAB, ctr[0] + OFFB + j * PA, ctr[1] + OFFB + j * PA, hi);
 #pragma unroll
                 for (int i = 0; i < V; ++i) {
-                    const float g = -(st[h][i] * dx[i] + ct[h][i] * dz[i]);
-                    cgA[h][i] = ct[h][i] * g, sg4[i] = st[h][i] * g;
+                    dx[i] += a1x[j] * (hi[i] - lo[i]);
+                    dz[i] += a1z[j] * (lb[P + i + j] - lb[P + i - j]);
                 }
-                *reinterpret_cast<vf4 *>(&sgA[(tx + P) * PG + V * (tl + TL * h)]) = sg4;
-                // the sums are complete HERE: left to itself the compiler moves them down to their use in the update and
-                // keeps the eleven quads they are formed from alive until then (registers spilled)
-#pragma unroll
-                for (int i = 0; i < V; ++i) asm volatile("" : "+v"(lap[h][i]), "+v"(cgA[h][i]));
             }
-            __builtin_amdgcn_sched_barrier(0);
-            {
-                float lb[V + 2 * P];   // z - P .. z + 3 + P
-                {
-                    const vf2 l2 = *reinterpret_cast<const vf2 *>(&sAB[ctr[h] + OFFB - 2]);
-                    const vf4 m4 = *reinterpret_cast<const vf4 *>(&sAB[ctr[h] + OFFB]);
-                    const vf2 r2 = *reinterpret_cast<const vf2 *>(&sAB[ctr[h] + OFFB + V]);
-                    if (P == 2) lb[0] = l2[0], lb[1] = l2[1], lb[V + 2] = r2[0], lb[V + 3] = r2[1];
-                    else lb[0] = l2[1], lb[V + 1] = r2[0];
+            vf2 sg[V];
 #pragma unroll
-                    for (int i = 0; i < V; ++i) lb[P + i] = m4[i];
-                }
-                float dx[V], dz[V];
-#pragma unroll
-                for (int i = 0; i < V; ++i) dx[i] = 0.f, dz[i] = 0.f;
-#pragma unroll
-                for (int j = 1; j <= P; ++j) {
-                    const vf4 lo = *reinterpret_cast<const vf4 *>(&sAB[ctr[h] + OFFB - j * PA]);
-                    const vf4 hi = *reinterpret_cast<const vf4 *>(&sAB[ctr[h] + OFFB + j * PA]);
-#pragma unroll
-                    for (int i = 0; i < V; ++i) {
-                        dx[i] += a1x[j] * (hi[i] - lo[i]);
-                        dz[i] += a1z[j] * (lb[P + i + j] - lb[P + i - j]);
-                    }
-                }
-                vf4 sg4;
-#pragma unroll
-                for (int i = 0; i < V; ++i) {
-                    const float g = -(st[h][i] * dx[i] + ct[h][i] * dz[i]);
-                    cgB[h][i] = ct[h][i] * g, sg4[i] = st[h][i] * g;
-                }
-                *reinterpret_cast<vf4 *>(&sgB[(tx + P) * PG + V * (tl + TL * h)]) = sg4;
-#pragma unroll
-                for (int i = 0; i < V; ++i) asm volatile("" : "+v"(cgB[h][i]));
+            for (int i = 0; i < V; ++i) {
+                const vf2 g = -(st[i] * dx[i] + ct[i] * dz[i]);
+                cgB[i] = ct[i] * g, sg[i] = st[i] * g;
             }
+            st2(sgB, (tx + P) * PG + V * tl, (tx + P) * PG + V * (tl + TL), sg);
+#pragma unroll
+            for (int i = 0; i < V; ++i) asm volatile("" : "+v"(cgB[i]));
         }
         __builtin_amdgcn_sched_barrier(0);
         // ---- the small tasks: cos * Gz on the columns beside the tile, sin * Gz on the rows above and below it --------
@@ -576,137 +583,146 @@ __global__ __launch_bounds__(128, 2) void persist_tti2d_kernel(PersistTtiArgs q)
             *reinterpret_cast<vf4 *>(&sgA[er * PG + V * hq]) = sa4;
             *reinterpret_cast<vf4 *>(&sgB[er * PG + V * hq]) = sb4;
         }
-        // cos * Gz of the quads beside this thread's two.  A row of the tile is four consecutive lanes and the
-        // permutations are cyclic within them: the quad left of quad l is the previous lane's first quad, except for
-        // lane 0, where it lies outside the tile; the quad right of quad l is the next lane's first quad, except for
-        // lane 3, where it is quad 4 = lane 0's second quad = the cyclically next lane's SECOND quad; likewise quad
-        // l + 4 has the previous lane's second quad to its left (lane 0: quad 3 = lane 3's first quad) and the next
-        // lane's second quad to its right (lane 3: outside the tile).  The two outside cases are filled in after the
-        // barrier from what the column tasks left in LDS.
         __syncthreads();
         // the saved levels are in LDS (vmcnt(0); waited for here, before this step's stores join the queue)
         if (GRAD) __builtin_amdgcn_s_waitcnt(0x0f70);
 
         // ---- update of both fields -------------------------------------------------------------------------------------
         const bool ragged = (fl & F_RAGGED) != 0;   // a row of the grid ends inside one of this lane's quads (rare)
+        __builtin_amdgcn_sched_barrier(0);
+        vf2 un[V], vn[V];
+        {
+            // the z lines of cos * Gz through the two quads.  A row of the tile is four consecutive lanes, and the
+            // permutations are cyclic within them.  Left of quad l lies the previous lane's first quad (lane 0: outside
+            // the tile, from the column tasks); right of it the next lane's first quad, except for lane 3, where it is
+            // quad 4 = lane 0's second quad = the cyclically next lane's SECOND quad.  Left of quad l + 4 lies the
+            // previous lane's second quad, except for lane 0, where it is quad 3 = the cyclically previous lane's FIRST
+            // quad; right of it the next lane's second quad (lane 3: outside the tile).
+            vf2 eA[V + 2 * P], eB[V + 2 * P];
 #pragma unroll
-        for (int h = 0; h < H; ++h) {
-            __builtin_amdgcn_sched_barrier(0);
-            float eA[V + 2 * P], eB[V + 2 * P];   // the z line of cos * Gz through quad h
-#pragma unroll
-            for (int i = 0; i < V; ++i) eA[P + i] = cgA[h][i], eB[P + i] = cgB[h][i];
+            for (int i = 0; i < V; ++i) eA[P + i] = cgA[i], eB[P + i] = cgB[i];
 #pragma unroll
             for (int i = 0; i < P; ++i) {
-                // A row of the tile is four consecutive lanes, and the permutations are cyclic within them.  Left of
-                // quad l lies the previous lane's first quad (lane 0: outside the tile, filled in below); right of it
-                // the next lane's first quad, except for lane 3, where it is quad 4 = lane 0's second quad = the
-                // cyclically next lane's SECOND quad.  Left of quad l + 4 lies the previous lane's second quad, except
-                // for lane 0, where it is quad 3 = the cyclically previous lane's FIRST quad; right of it the next
-                // lane's second quad (lane 3: outside the tile).
-                if (h == 0) {
-                    eA[i] = quad_rotate<true>(cgA[0][V - P + i]), eB[i] = quad_rotate<true>(cgB[0][V - P + i]);
-                    const float na0 = quad_rotate<false>(cgA[0][i]), na1 = quad_rotate<false>(cgA[1][i]);
-                    const float nv0 = quad_rotate<false>(cgB[0][i]), nv1 = quad_rotate<false>(cgB[1][i]);
-                    eA[P + V + i] = (fl & F_RIGHT) ? na1 : na0, eB[P + V + i] = (fl & F_RIGHT) ? nv1 : nv0;
-                } else {
-                    const float pa0 = quad_rotate<true>(cgA[0][V - P + i]), pa1 = quad_rotate<true>(cgA[1][V - P + i]);
-                    const float pv0 = quad_rotate<true>(cgB[0][V - P + i]), pv1 = quad_rotate<true>(cgB[1][V - P + i]);
-                    eA[i] = (fl & F_LEFT) ? pa0 : pa1, eB[i] = (fl & F_LEFT) ? pv0 : pv1;
-                    eA[P + V + i] = quad_rotate<false>(cgA[1][i]), eB[P + V + i] = quad_rotate<false>(cgB[1][i]);
-                }
+                const float pa0 = quad_rotate<true>(cgA[V - P + i][0]), pa1 = quad_rotate<true>(cgA[V - P + i][1]);
+                const float pv0 = quad_rotate<true>(cgB[V - P + i][0]), pv1 = quad_rotate<true>(cgB[V - P + i][1]);
+                const float na0 = quad_rotate<false>(cgA[i][0]), na1 = quad_rotate<false>(cgA[i][1]);
+                const float nv0 = quad_rotate<false>(cgB[i][0]), nv1 = quad_rotate<false>(cgB[i][1]);
+                eA[i] = vf2{pa0, (fl & F_LEFT) ? pa0 : pa1}, eB[i] = vf2{pv0, (fl & F_LEFT) ? pv0 : pv1};
+                eA[P + V + i] = vf2{(fl & F_RIGHT) ? na1 : na0, na1}, eB[P + V + i] = vf2{(fl & F_RIGHT) ? nv1 : nv0, nv1};
             }
-            if (h == 0 && (fl & F_LEFT)) {
+            if (fl & F_LEFT) {
 #pragma unroll
-                for (int i = 0; i < P; ++i) eA[i] = zh[0][0][tx][i], eB[i] = zh[1][0][tx][i];
+                for (int i = 0; i < P; ++i) eA[i][0] = zh[0][0][tx][i], eB[i][0] = zh[1][0][tx][i];
             }
-            if (h == 1 && (fl & F_RIGHT)) {
+            if (fl & F_RIGHT) {
 #pragma unroll
-                for (int i = 0; i < P; ++i) eA[P + V + i] = zh[0][1][tx][i], eB[P + V + i] = zh[1][1][tx][i];
+                for (int i = 0; i < P; ++i) eA[P + V + i][1] = zh[0][1][tx][i], eB[P + V + i][1] = zh[1][1][tx][i];
             }
-            float un[V], vn[V];
-            const int gq = (tx + P) * PG + V * (tl + TL * h);
-            float sa[V], sb[V];
+            const int gq0 = (tx + P) * PG + V * tl, gq1 = gq0 + V * TL;
+            vf2 sa[V], sb[V];
 #pragma unroll
-            for (int i = 0; i < V; ++i) sa[i] = 0.f, sb[i] = 0.f;
+            for (int i = 0; i < V; ++i) sa[i] = vf2{0.f, 0.f}, sb[i] = vf2{0.f, 0.f};
 #pragma unroll
             for (int j = 1; j <= P; ++j) {
-                const vf4 alo = *reinterpret_cast<const vf4 *>(&sgA[gq - j * PG]);
-                const vf4 ahi = *reinterpret_cast<const vf4 *>(&sgA[gq + j * PG]);
-                const vf4 blo = *reinterpret_cast<const vf4 *>(&sgB[gq - j * PG]);
-                const vf4 bhi = *reinterpret_cast<const vf4 *>(&sgB[gq + j * PG]);
+                vf2 alo[V], ahi[V];
+                ld2(sgA, gq0 - j * PG, gq1 - j * PG, alo);
+                ld2(sgA, gq0 + j * PG, gq1 + j * PG, ahi);
 #pragma unroll
                 for (int i = 0; i < V; ++i) {
                     sa[i] += a1z[j] * (eA[P + i + j] - eA[P + i - j]);
                     sa[i] += a1x[j] * (ahi[i] - alo[i]);
+                }
+            }
+#pragma unroll
+            for (int j = 1; j <= P; ++j) {
+                vf2 blo[V], bhi[V];
+                ld2(sgB, gq0 - j * PG, gq1 - j * PG, blo);
+                ld2(sgB, gq0 + j * PG, gq1 + j * PG, bhi);
+#pragma unroll
+                for (int i = 0; i < V; ++i) {
                     sb[i] += a1z[j] * (eB[P + i + j] - eB[P + i - j]);
                     sb[i] += a1x[j] * (bhi[i] - blo[i]);
                 }
             }
 #pragma unroll
             for (int i = 0; i < V; ++i) {
-                const float X = lap[h][i] + sa[i], Y = -sb[i];   // Gxx = laplace - Gzz with Gzz = -sa
-                const float H0 = FWD ? et[h][i] * X + dl[h][i] * Y : X;
-                const float Hz = FWD ? dl[h][i] * X + Y : Y;
-                const float uc = ucur[h][i], vc = vcur[h][i], mz = mm[h][i], e = ed[h][i], b = mz + e, rb = tti_rcp(b);
-                un[i] = tti_div(dt2l[h] * H0 + 2.0f * mz * uc - mz * uold[h][i] + e * uc, b, rb);
-                vn[i] = tti_div(dt2l[h] * Hz + 2.0f * mz * vc - mz * vold[h][i] + e * vc, b, rb);
+                const vf2 X = lap[i] + sa[i], Y = -sb[i];   // Gxx = laplace - Gzz with Gzz = -sa
+                const vf2 H0 = FWD ? et[i] * X + dl[i] * Y : X;
+                const vf2 Hz = FWD ? dl[i] * X + Y : Y;
+                const vf2 uc = ucur[i], vc = vcur[i], mz = mm[i], e = ed[i], b = mz + e;
+                vf2 rb = vf2{__builtin_amdgcn_rcpf(b[0]), __builtin_amdgcn_rcpf(b[1])};
+                rb = __builtin_elementwise_fma(__builtin_elementwise_fma(-b, rb, vf2{1.0f, 1.0f}), rb, rb);
+                const vf2 nu = dt2p * H0 + 2.0f * mz * uc - mz * uold[i] + e * uc;
+                const vf2 nv = dt2p * Hz + 2.0f * mz * vc - mz * vold[i] + e * vc;
+                const vf2 qu = nu * rb, qv = nv * rb;
+                un[i] = __builtin_elementwise_fma(__builtin_elementwise_fma(-b, qu, nu), rb, qu);
+                vn[i] = __builtin_elementwise_fma(__builtin_elementwise_fma(-b, qv, nv), rb, qv);
             }
-            if (ninj > 0) {
-                const vf4 add = *reinterpret_cast<const vf4 *>(&acc[tx * TZ + V * (tl + TL * h)]);
+        }
+        if (ninj > 0) {
+            vf2 add[V];
+            ld2(acc, tx * TZ + V * tl, tx * TZ + V * (tl + TL), add);
 #pragma unroll
-                for (int i = 0; i < V; ++i) un[i] += add[i], vn[i] += add[i];
-            }
-            if (__builtin_expect(ragged, 0)) {
-                // points past the end of a row are halo: they stay zero in the registers as they do in memory
-                const int n2 = q.a.n2;
+            for (int i = 0; i < V; ++i) un[i] += add[i], vn[i] += add[i];
+        }
+        if (__builtin_expect(ragged, 0)) {
+            // points past the end of a row are halo: they stay zero in the registers as they do in memory
+            const int n2 = q.a.n2;
 #pragma unroll
-                for (int i = 0; i < V; ++i)
-                    if (zq[h] + i >= n2) un[i] = 0.f, vn[i] = 0.f;
-            }
-            vf4 ca, cb;   // backward loops: the stencilled combinations of the new levels, for the neighbours
+            for (int i = 0; i < V; ++i)
 #pragma unroll
-            for (int i = 0; i < V; ++i) ca[i] = et[h][i] * un[i] + dl[h][i] * vn[i], cb[i] = dl[h][i] * un[i] + vn[i];
-            if (!FWD) {
-                // they are the next step's stencilled fields at this thread's points: nobody reads the image any more
-                // in this step (its last readers finished before the barrier above)
-                *reinterpret_cast<vf4 *>(&sAB[ctr[h]]) = ca;
-                *reinterpret_cast<vf4 *>(&sAB[ctr[h] + OFFB]) = cb;
-            }
-            if (__builtin_expect(!ragged, 1)) {
-                store_f4_held<kPlain>(vf4{un[0], un[1], un[2], un[3]}, rotuB, (int)pb[h], (int)out_off);
-                store_f4_held<kPlain>(vf4{vn[0], vn[1], vn[2], vn[3]}, rotvB, (int)pb[h], (int)out_off);
+                for (int h = 0; h < H; ++h)
+                    if (zq[h] + i >= n2) un[i][h] = 0.f, vn[i][h] = 0.f;
+        }
+        vf2 ca[V], cb[V];   // backward loops: the stencilled combinations of the new levels, for the neighbours
+#pragma unroll
+        for (int i = 0; i < V; ++i) ca[i] = et[i] * un[i] + dl[i] * vn[i], cb[i] = dl[i] * un[i] + vn[i];
+        if (!FWD) {
+            // they are the next step's stencilled fields at this thread's points: nobody reads the image any more
+            // in this step (its last readers finished before the barrier above)
+            st2(sAB, ctr[0], ctr[1], ca);
+            st2(sAB, ctr[0] + OFFB, ctr[1] + OFFB, cb);
+        }
+        if (__builtin_expect(!ragged, 1)) {
+#pragma unroll
+            for (int h = 0; h < H; ++h) {
+                store_f4_held<kPlain>(vf4{un[0][h], un[1][h], un[2][h], un[3][h]}, rotuB, (int)pb[h], (int)out_off);
+                store_f4_held<kPlain>(vf4{vn[0][h], vn[1][h], vn[2][h], vn[3][h]}, rotvB, (int)pb[h], (int)out_off);
                 if (!FWD) {
-                    store_f4_held<kPlain>(ca, exaB, (int)pb[h], (int)ex_out);
-                    store_f4_held<kPlain>(cb, exbB, (int)pb[h], (int)ex_out);
+                    store_f4_held<kPlain>(vf4{ca[0][h], ca[1][h], ca[2][h], ca[3][h]}, exaB, (int)pb[h], (int)ex_out);
+                    store_f4_held<kPlain>(vf4{cb[0][h], cb[1][h], cb[2][h], cb[3][h]}, exbB, (int)pb[h], (int)ex_out);
                 }
-            } else {
-                const int n2 = q.a.n2;
+            }
+        } else {
+            const int n2 = q.a.n2;
+#pragma unroll 1
+            for (int h = 0; h < H; ++h) {
                 const long e0 = (long)q.a.off0 + (long)x * q.a.s1 + zq[h];
                 float *pu = q.rot_u + ((long)shot * 3 + (time + dir + 3) % 3) * q.field + e0;
                 float *pv = q.rot_v + ((long)shot * 3 + (time + dir + 3) % 3) * q.field + e0;
                 float *pa = FWD ? nullptr : q.comb_a + ((long)shot * 2 + ((s + 1) & 1)) * q.field + e0;
                 float *pc = FWD ? nullptr : q.comb_b + ((long)shot * 2 + ((s + 1) & 1)) * q.field + e0;
-#pragma unroll
                 for (int i = 0; i < V; ++i)
                     if (zq[h] + i < n2) {
-                        pu[i] = un[i], pv[i] = vn[i];
-                        if (!FWD) pa[i] = ca[i], pc[i] = cb[i];
+                        pu[i] = h ? un[i][1] : un[i][0], pv[i] = h ? vn[i][1] : vn[i][0];
+                        if (!FWD) pa[i] = h ? ca[i][1] : ca[i][0], pc[i] = h ? cb[i][1] : cb[i][0];
                     }
             }
-            if (GRAD) {
-                // summed by parts over time (see tti2d_kernel): the second time difference is taken of the adjoint fields
-                const vf4 su4 = *reinterpret_cast<const vf4 *>(&ssave[((0 * H + h) * NT + tid) * V]);
-                const vf4 sv4 = *reinterpret_cast<const vf4 *>(&ssave[((1 * H + h) * NT + tid) * V]);
-#pragma unroll
-                for (int i = 0; i < V; ++i) {
-                    const float ptt = (uold[h][i] - 2.0f * ucur[h][i] + un[i]) * a.inv_dt2;
-                    const float rtt = (vold[h][i] - 2.0f * vcur[h][i] + vn[i]) * a.inv_dt2;
-                    gsum[h][i] += -(ptt * su4[i] + rtt * sv4[i]);
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < V; ++i) uold[h][i] = ucur[h][i], ucur[h][i] = un[i], vold[h][i] = vcur[h][i], vcur[h][i] = vn[i];
         }
+        if (GRAD) {
+            // summed by parts over time (see tti2d_kernel): the second time difference is taken of the adjoint fields
+            vf2 su2[V], sv2[V];
+            ld2(ssave, ((0 * H + 0) * NT + tid) * V, ((0 * H + 1) * NT + tid) * V, su2);
+            ld2(ssave, ((1 * H + 0) * NT + tid) * V, ((1 * H + 1) * NT + tid) * V, sv2);
+#pragma unroll
+            for (int i = 0; i < V; ++i) {
+                const vf2 ptt = (uold[i] - 2.0f * ucur[i] + un[i]) * a.inv_dt2;
+                const vf2 rtt = (vold[i] - 2.0f * vcur[i] + vn[i]) * a.inv_dt2;
+                gsum[i] += -(ptt * su2[i] + rtt * sv2[i]);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < V; ++i) uold[i] = ucur[i], ucur[i] = un[i], vold[i] = vcur[i], vcur[i] = vn[i];
 
         // publish: this wave's stores have reached the L2, then every wave's, then the counter moves
         __builtin_amdgcn_s_waitcnt(0);
@@ -718,15 +734,18 @@ __global__ __launch_bounds__(128, 2) void persist_tti2d_kernel(PersistTtiArgs q)
         if (q.save_u) {
             float *pu = q.save_u + (long)shot * q.save_shot_stride + (long)(time + 1) * q.field;
             float *pv = q.save_v + (long)shot * q.save_shot_stride + (long)(time + 1) * q.field;
+            if (__builtin_expect(!ragged, 1)) {
 #pragma unroll
-            for (int h = 0; h < H; ++h) {
-                if (__builtin_expect(!ragged, 1)) {
-                    store_f4_held<kStream>(vf4{ucur[h][0], ucur[h][1], ucur[h][2], ucur[h][3]}, tbuf_of(pu), (int)pb[h], 0);
-                    store_f4_held<kStream>(vf4{vcur[h][0], vcur[h][1], vcur[h][2], vcur[h][3]}, tbuf_of(pv), (int)pb[h], 0);
-                } else {
+                for (int h = 0; h < H; ++h) {
+                    store_f4_held<kStream>(vf4{ucur[0][h], ucur[1][h], ucur[2][h], ucur[3][h]}, tbuf_of(pu), (int)pb[h], 0);
+                    store_f4_held<kStream>(vf4{vcur[0][h], vcur[1][h], vcur[2][h], vcur[3][h]}, tbuf_of(pv), (int)pb[h], 0);
+                }
+            } else {
+#pragma unroll 1
+                for (int h = 0; h < H; ++h) {
                     const long e0 = (long)q.a.off0 + (long)x * q.a.s1 + zq[h];
                     for (int i = 0; i < V; ++i)
-                        if (zq[h] + i < q.a.n2) pu[e0 + i] = ucur[h][i], pv[e0 + i] = vcur[h][i];
+                        if (zq[h] + i < q.a.n2) pu[e0 + i] = h ? ucur[i][1] : ucur[i][0], pv[e0 + i] = h ? vcur[i][1] : vcur[i][0];
                 }
             }
         }
@@ -738,7 +757,7 @@ __global__ __launch_bounds__(128, 2) void persist_tti2d_kernel(PersistTtiArgs q)
             if (!(flags & (h ? F_LIVE1 : F_LIVE0))) continue;
             float *gp = q.grad + (long)shot * q.g_shot_stride + at(x, zq[h]);
             for (int i = 0; i < V; ++i)
-                if (zq[h] + i < a.n2) gp[i] = gsum[h][i];
+                if (zq[h] + i < a.n2) gp[i] = h ? gsum[i][1] : gsum[i][0];
         }
     }
 }
