@@ -426,6 +426,14 @@ template int launch_sparse<double>(const Plan &, const SparsePtrs<double> &, int
 // with zx, zz, c^2 of the phi equations taken at the staggered point (c^2: mean of 1/m over the cell's
 // corners inside the grid).  Fields are zero outside the grid (halo), as everywhere in this library.
 // ------------------------------------------------------------------------------------------
+// node (i1, i2) lies in a layer region: the subdomains d1-d3 of the notebook (cells 20-22), for any choice of sides
+template <typename T>
+__device__ inline bool pml_in_layer(const PmlPtrs<T> &q, const StepConsts<T> &k, int i1, int i2)
+{
+    return ((q.sides & 1) && i1 < q.npml) || ((q.sides & 2) && i1 >= k.n1 - q.npml) || ((q.sides & 4) && i2 < q.npml) ||
+           ((q.sides & 8) && i2 >= k.n2 - q.npml);
+}
+
 template <typename T, int R>
 __global__ __launch_bounds__(256) void pml_u_kernel(StepConsts<T> k, PmlPtrs<T> q)
 {
@@ -443,7 +451,23 @@ __global__ __launch_bounds__(256) void pml_u_kernel(StepConsts<T> k, PmlPtrs<T> 
     const T zx = q.zx0[i1], zz = q.zz0[i2];
     const T h = T(0.5) * (zx + zz) * k.dt;
     const T rhs = T(2) * uc - uo * (T(1) - h) + k.dt2 * (lap / q.m[p] - zx * zz * uc - P1 - P2);
-    q.out[(long)shot * q.shot_stride + p] = rhs / (T(1) + h);
+    T un = rhs / (T(1) + h);
+    // the notebook's layout: outside the layer regions the plain wave equation, without the auxiliary terms
+    if (q.edges && !pml_in_layer(q, k, i1, i2)) un = T(2) * uc - uo + k.dt2 * (lap / q.m[p]);
+    q.out[(long)shot * q.shot_stride + p] = un;
+}
+
+// Boundary rows of the notebook (03_pml.ipynb cell 83), after the source term: u = 0 on the first and last x node and on
+// the last z node, u[x, 0] = u[x, 1].
+template <typename T>
+__global__ __launch_bounds__(256) void pml_edges_kernel(StepConsts<T> k, T *out, long shot_stride)
+{
+    const int i2 = blockIdx.x * 64 + threadIdx.x;
+    const int i1 = blockIdx.y * 4 + threadIdx.y;
+    if (i2 >= k.n2 || i1 >= k.n1) return;
+    T *u = out + (long)blockIdx.z * shot_stride + k.off0 + (long)i1 * k.s1;
+    if (i1 == 0 || i1 == k.n1 - 1 || i2 == k.n2 - 1) u[i2] = T(0);
+    else if (i2 == 0) u[0] = u[1];
 }
 
 template <typename T>
@@ -456,7 +480,7 @@ __global__ __launch_bounds__(256) void pml_phi_kernel(StepConsts<T> k, PmlPtrs<T
     const long p = k.off0 + (long)i1 * k.s1 + i2;
     const T zx = q.zx1[i1], zz = q.zz1[i2];
     const long ps = (long)shot * q.phi_shot_stride + p;
-    if (zx == T(0) && zz == T(0)) {   // outside the layer the auxiliary fields stay zero
+    if (q.edges ? !pml_in_layer(q, k, i1, i2) : (zx == T(0) && zz == T(0))) {   // outside the layer the auxiliary fields stay zero
         q.phi1_out[ps] = T(0), q.phi2_out[ps] = T(0);
         return;
     }
@@ -472,6 +496,7 @@ __global__ __launch_bounds__(256) void pml_phi_kernel(StepConsts<T> k, PmlPtrs<T
     if (zin) c2 += T(1) / q.m[p + 1], ++nc;
     if (xin && zin) c2 += T(1) / q.m[p + sx + 1], ++nc;
     c2 /= T(nc);
+    if (q.c2s) c2 = q.c2s[p];   // the caller's own velocity at the staggered points (the notebook's vel1), squared
     const T idt = T(1) / k.dt;
     q.phi1_out[ps] = (q.phi1[ps] * (idt - T(0.5) * zx) + (zz - zx) * c2 * T(0.25) * q.ihx * a) / (idt + T(0.5) * zx);
     q.phi2_out[ps] = (q.phi2[ps] * (idt - T(0.5) * zz) + (zx - zz) * c2 * T(0.25) * q.ihz * b) / (idt + T(0.5) * zz);
@@ -502,6 +527,16 @@ int launch_pml_phi(const Plan &p, const StepConsts<T> &k, const PmlPtrs<T> &q, i
     MIFWI_HIP(hipGetLastError());
     return MIFWI_OK;
 }
+template <typename T>
+int launch_pml_edges(const Plan &p, const StepConsts<T> &k, T *out, long shot_stride, int nshots)
+{
+    const dim3 block(64, 4, 1), grid((k.n2 + 63) / 64, (k.n1 + 3) / 4, (unsigned)nshots);
+    hipLaunchKernelGGL((pml_edges_kernel<T>), grid, block, 0, p.stream, k, out, shot_stride);
+    MIFWI_HIP(hipGetLastError());
+    return MIFWI_OK;
+}
+template int launch_pml_edges<float>(const Plan &, const StepConsts<float> &, float *, long, int);
+template int launch_pml_edges<double>(const Plan &, const StepConsts<double> &, double *, long, int);
 template int launch_pml_u<float>(const Plan &, const StepConsts<float> &, const PmlPtrs<float> &, int);
 template int launch_pml_u<double>(const Plan &, const StepConsts<double> &, const PmlPtrs<double> &, int);
 template int launch_pml_phi<float>(const Plan &, const StepConsts<float> &, const PmlPtrs<float> &, int);
@@ -547,6 +582,21 @@ int launch_prep_model(const Plan &p, const T *vp, const T *damp, T *m, T *eta)
 }
 template int launch_prep_model<float>(const Plan &, const float *, const float *, float *, float *);
 template int launch_prep_model<double>(const Plan &, const double *, const double *, double *, double *);
+
+template <typename T>
+__global__ void square_kernel(T *a, long n)
+{
+    for (long g = blockIdx.x * (long)blockDim.x + threadIdx.x; g < n; g += (long)gridDim.x * blockDim.x) a[g] = a[g] * a[g];
+}
+template <typename T>
+int launch_square(const Plan &p, T *a, long n)
+{
+    hipLaunchKernelGGL((square_kernel<T>), dim3((int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096)), dim3(256), 0, p.stream, a, n);
+    MIFWI_HIP(hipGetLastError());
+    return MIFWI_OK;
+}
+template int launch_square<float>(const Plan &, float *, long);
+template int launch_square<double>(const Plan &, double *, long);
 
 template <typename T, int MODE>
 __global__ void unpack_kernel(DenseMap d, const T *haloed, long shot_stride, T *dense)

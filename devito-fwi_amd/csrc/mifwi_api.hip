@@ -166,6 +166,7 @@ static void destroy(Plan *p)
     dev_free(p->d_dm);
     dev_free(p->pml_phi);
     dev_free(p->pml_zeta);
+    dev_free(p->pml_c2s);
     dev_free(p->d_winj[0]);
     dev_free(p->d_winj[1]);
     dev_free(p->d_psync);
@@ -1797,24 +1798,41 @@ static int l2_misfit_gradient(Plan &p, int nshots, const void *wavelet, int per_
 // Damping profiles of the perfectly matched layer (fdamp of seismic/abc_methods/03_pml.ipynb cell 60): along a
 // dimension of n nodes, a = depth into the npml-cell layer / its width at node i and at the staggered point i + 1/2
 template <typename T>
-static int set_pml(Plan &p, int npml, double quibar)
+static int set_pml(Plan &p, int npml, double quibar, int sides, int edges, const void *vp_staggered)
 {
     if (!(p.cfg.flags & MIFWI_FLAG_PML)) return fail(MIFWI_ESTATE, "the plan was not created with MIFWI_FLAG_PML");
     if (npml < 1 || 2 * npml >= std::min(p.L.n[1], p.L.n[2]) || !(quibar >= 0.0))
         return fail(MIFWI_EINVAL, "npml must be positive and leave an interior; quibar must not be negative");
+    if (sides < 0 || sides > 15 || (edges != 0 && edges != 1)) return fail(MIFWI_EINVAL, "sides is a mask of 4 bits, edges 0 or 1");
     const int n1 = p.L.n[1], n2 = p.L.n[2];
     std::vector<T> z(2 * (size_t)(n1 + n2));
-    auto zeta = [&](double pos, int n) {   // pos: node coordinate in cells
+    auto zeta = [&](double pos, int n, bool low, bool high) {   // pos: node coordinate in cells
         double a = 0.0;
-        if (pos <= npml) a = (npml - pos) / npml;
-        else if (pos >= n - 1 - npml) a = (pos - (n - 1 - npml)) / npml;
+        if (low && pos <= npml) a = (npml - pos) / npml;
+        else if (high && pos >= n - 1 - npml) a = (pos - (n - 1 - npml)) / npml;
         return (T)(quibar * (a - std::sin(2.0 * M_PI * a) / (2.0 * M_PI)));
     };
-    for (int i = 0; i < n1; ++i) z[i] = zeta(i, n1), z[n1 + n2 + i] = zeta(i + 0.5, n1);
-    for (int i = 0; i < n2; ++i) z[n1 + i] = zeta(i, n2), z[2 * n1 + n2 + i] = zeta(i + 0.5, n2);
+    for (int i = 0; i < n1; ++i) z[i] = zeta(i, n1, sides & 1, sides & 2), z[n1 + n2 + i] = zeta(i + 0.5, n1, sides & 1, sides & 2);
+    for (int i = 0; i < n2; ++i) z[n1 + i] = zeta(i, n2, sides & 4, sides & 8), z[2 * n1 + n2 + i] = zeta(i + 0.5, n2, sides & 4, sides & 8);
+    if (edges) {   // the notebook's staggered profiles repeat their last entry (cells 72-74)
+        z[n1 + n2 + n1 - 1] = z[n1 + n2 + n1 - 2];
+        z[2 * n1 + n2 + n2 - 1] = z[2 * n1 + n2 + n2 - 2];
+    }
     MIFWI_HIP(hipMemcpyAsync(p.pml_zeta, z.data(), z.size() * sizeof(T), hipMemcpyHostToDevice, p.stream));
+    int rc;
+    if (vp_staggered) {
+        // squared, in the haloed layout of a field level
+        if (!p.pml_c2s && (rc = dev_alloc(p, &p.pml_c2s, (size_t)p.L.field * sizeof(T), true))) return rc;
+        if ((rc = copy_any(p, p.d_dense, vp_staggered, (size_t)p.L.ngrid * sizeof(T)))) return rc;
+        if ((rc = launch_pack<T>(p, (const T *)p.d_dense, (T *)p.pml_c2s, p.L.field, 1))) return rc;
+        if ((rc = launch_square<T>(p, (T *)p.pml_c2s, p.L.field))) return rc;
+    } else if (p.pml_c2s) {
+        dev_free(p.pml_c2s);
+        p.pml_c2s = nullptr;
+    }
     MIFWI_HIP(hipStreamSynchronize(p.stream));
     clear_graphs(p);
+    p.pml_sides = sides, p.pml_edges = edges, p.pml_npml = npml;
     p.have_pml = true;
     return MIFWI_OK;
 }
@@ -1850,6 +1868,7 @@ static int run_forward_pml(Plan &p, int nshots)
             q.phi1_out = phi + on, q.phi2_out = phi + 2 * L.field + on;
             q.phi_shot_stride = phi_stride;
             q.ihx = (T)(1.0 / p.cfg.spacing[0]), q.ihz = (T)(1.0 / p.cfg.spacing[1]);
+            q.sides = p.pml_sides, q.npml = p.pml_npml, q.edges = p.pml_edges, q.c2s = (const T *)p.pml_c2s;
             int r;
             if ((r = launch_pml_u<T>(p, k, q, nshots))) return r;
             SparsePtrs<T> sq{};
@@ -1857,6 +1876,10 @@ static int run_forward_pml(Plan &p, int nshots)
             sq.itp = &p.rec, sq.field_int = q.cur, sq.vals_out = (T *)p.d_rec;
             sq.shot_stride = shot_stride, sq.m = (const T *)p.m, sq.time = time, sq.nt = nt, sq.dt2 = k.dt2;
             if ((r = launch_sparse<T>(p, sq, nshots))) return r;
+            if (p.pml_edges) {
+                if ((r = launch_pml_edges<T>(p, k, q.out, shot_stride, nshots))) return r;
+                launches += 1;
+            }
             if ((r = launch_pml_phi<T>(p, k, q, nshots))) return r;
             launches += 3;
         }
@@ -2755,7 +2778,14 @@ int mifwi_l2_misfit_gradient(mifwi_plan *plan, int32_t nshots, const void *wavel
 int mifwi_set_pml(mifwi_plan *plan, int32_t npml, double quibar)
 {
     PLAN_OR_FAIL(plan);
-    GUARDED(DISPATCH(set_pml<float>(p, npml, quibar), set_pml<double>(p, npml, quibar)));
+    GUARDED(DISPATCH(set_pml<float>(p, npml, quibar, 15, 0, nullptr), set_pml<double>(p, npml, quibar, 15, 0, nullptr)));
+}
+
+int mifwi_set_pml_layout(mifwi_plan *plan, int32_t npml, double quibar, int32_t sides, int32_t edges, const void *vp_staggered)
+{
+    PLAN_OR_FAIL(plan);
+    GUARDED(DISPATCH(set_pml<float>(p, npml, quibar, sides, edges, vp_staggered),
+                     set_pml<double>(p, npml, quibar, sides, edges, vp_staggered)));
 }
 
 int mifwi_l2_misfit(mifwi_plan *plan, int32_t nshots, const void *syn, const void *obs, void *residual_out, double *fval)

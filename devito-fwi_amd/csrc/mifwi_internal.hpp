@@ -158,8 +158,9 @@ struct Plan {
     size_t winj_elems[2] = {0, 0};
     // MIFWI_FLAG_PML: auxiliary fields [max_shots][phi1 | phi2][2 levels][field] and damping profiles
     // [zeta_x nodes | zeta_z nodes | zeta_x staggered | zeta_z staggered], n1 + n2 + n1 + n2 values
-    void *pml_phi = nullptr, *pml_zeta = nullptr;
+    void *pml_phi = nullptr, *pml_zeta = nullptr, *pml_c2s = nullptr;
     bool have_pml = false;
+    int pml_sides = 15, pml_edges = 0, pml_npml = 0;
     void *d_dm = nullptr;                    // [field] haloed model perturbation of the Born operator
     void *d_dense = nullptr;                 // dense staging, max(max_shots*ngrid, ...) elements
     size_t dense_elems = 0;
@@ -294,7 +295,13 @@ struct PmlPtrs {
     T *phi1_out, *phi2_out;  // and at t+1
     long phi_shot_stride;
     T ihx, ihz;              // 1 / spacing
+    // layout: sides that have a layer (bit 0 low x, 1 high x, 2 low z, 3 high z), its width in nodes, whether the
+    // notebook's regions and boundary rows apply, and the caller's c^2 at the staggered points (null: corner mean)
+    int sides, npml, edges;
+    const T *c2s;
 };
+template <typename T>
+int launch_pml_edges(const Plan &p, const StepConsts<T> &k, T *out, long shot_stride, int nshots);
 template <typename T>
 int launch_pml_u(const Plan &p, const StepConsts<T> &k, const PmlPtrs<T> &q, int nshots);
 template <typename T>
@@ -305,6 +312,9 @@ template <typename T>
 int launch_unpack(const Plan &p, const T *haloed, long shot_stride, T *dense, int nshots, int mode);
 template <typename T>
 int launch_pack(const Plan &p, const T *dense, T *haloed, long shot_stride, int nshots);
+// a[i] *= a[i] over n elements
+template <typename T>
+int launch_square(const Plan &p, T *a, long n);
 
 // res = syn - obs ; fval[shot] = 0.5 * sum res^2 (f64, deterministic two-stage reduction)
 template <typename T>

@@ -18,7 +18,7 @@ EXPORTED_SYMBOLS = (
     "mifwi_gradient", "mifwi_l2_misfit_gradient", "mifwi_read_wavefield", "mifwi_write_wavefield",
     "mifwi_get_stats", "mifwi_born", "mifwi_tti_set_model", "mifwi_tti_forward", "mifwi_tti_adjoint",
     "mifwi_tti_born", "mifwi_tti_gradient", "mifwi_l2_misfit", "mifwi_l2_misfit_noalloc",
-    "mifwi_set_pml", "mifwi_sum_shots", "mifwi_precondition",
+    "mifwi_set_pml", "mifwi_set_pml_layout", "mifwi_sum_shots", "mifwi_precondition",
 )
 
 
@@ -98,6 +98,7 @@ def load_library():
     lib.mifwi_gradient.argtypes = [vp, i32, vp, vp, i32, vp]
     lib.mifwi_l2_misfit_gradient.argtypes = [vp, i32, vp, i32, vp, vp, vp, vp, vp, vp]
     lib.mifwi_set_pml.argtypes = [vp, i32, ctypes.c_double]
+    lib.mifwi_set_pml_layout.argtypes = [vp, i32, ctypes.c_double, i32, i32, vp]
     lib.mifwi_l2_misfit.argtypes = [vp, i32, vp, vp, vp, vp]
     lib.mifwi_l2_misfit_noalloc.argtypes = [i32, i32, ctypes.c_int64, vp, vp, vp, vp, vp]
     lib.mifwi_sum_shots.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp]
@@ -248,9 +249,16 @@ class Plan(object):
         # allocator before the plan has waited, so they are held until the next model replaces them
         self._model_keep = (kv, kd)
 
-    def set_pml(self, npml, quibar=0.05):
-        """Layer width (cells) and strength of a FLAG_PML plan."""
-        self._check(self._lib.mifwi_set_pml(self._h, int(npml), float(quibar)))
+    def set_pml(self, npml, quibar=0.05, sides=None, edges=False, vp_staggered=None):
+        """Layer width (cells) and strength of a FLAG_PML plan.  sides: (low x, high x, low z, high z) booleans, default
+        all; edges=True: regions and boundary rows as the reference's notebook has them; vp_staggered: the caller's
+        velocity at the staggered points (padded grid)."""
+        if sides is None and not edges and vp_staggered is None:
+            self._check(self._lib.mifwi_set_pml(self._h, int(npml), float(quibar)))
+            return
+        mask = 15 if sides is None else sum(1 << k for k, on in enumerate(sides) if on)
+        pv, kv = self._in(vp_staggered)
+        self._check(self._lib.mifwi_set_pml_layout(self._h, int(npml), float(quibar), mask, int(bool(edges)), pv))
 
     def set_geometry(self, src_coords, rec_coords, rec_per_shot=False, nshots=None):
         sc = np.ascontiguousarray(src_coords, dtype=self.dtype)

@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define MIFWI_VERSION 102
+#define MIFWI_VERSION 103
 
 enum {
     MIFWI_OK = 0,
@@ -225,6 +225,18 @@ MIFWI_API int mifwi_l2_misfit_gradient(mifwi_plan *plan, int32_t nshots, const v
  * seismic/abc_methods/03_pml.ipynb cell 60, where quibar = 0.05), evaluated at the nodes and at the
  * half-way (staggered) points.  Must be called before mifwi_forward. */
 MIFWI_API int mifwi_set_pml(mifwi_plan *plan, int32_t npml, double quibar);
+
+/* The same layer with the layout of the reference's notebook spelled out (seismic/abc_methods/03_pml.ipynb):
+ * sides: bit 0 / 1 = layer at the first / last nodes of x, bit 2 / 3 = of z (the notebook: 1 | 2 | 8, none at the top,
+ * cell 58; mifwi_set_pml: all four).  edges = 1: the damped update and the auxiliary fields only at the nodes of the
+ * layer regions (its subdomains d1-d3, cells 20-22 and 76-81), the plain wave equation elsewhere, the staggered
+ * profiles' last entry repeated (cells 72-74) and, after the source term of every step, the boundary rows of cell 83
+ * (u = 0 on the first and last x node and on the last z node, u[x, 0] = u[x, 1]); edges = 0: fields zero outside the
+ * grid as everywhere in this library.  vp_staggered: NULL (c^2 at a staggered point = mean of c^2 over the cell's
+ * corners inside the grid) or the caller's own velocity at the staggered points over the padded grid (the notebook's
+ * vel1, cells 26 and 51-53). */
+MIFWI_API int mifwi_set_pml_layout(mifwi_plan *plan, int32_t npml, double quibar, int32_t sides, int32_t edges,
+                                   const void *vp_staggered);
 
 /* Replaces: least_square(syn, obs) of misfit/misfit.py:5-9 as fwi.py:151 calls it between the forward and the
  * gradient pass, on gathers that are already on the device: residual_out = syn - obs and

@@ -408,10 +408,15 @@ def fwi_obj_multi(prob, src_positions, rec_pos, wavelet, obs_list, dt=None, mask
 # cell only bounds ||rec|| to within a factor of two): parity of the GPU path is against this
 # restatement, which is itself constrained by properties (tests/test_pml.py).
 # ----------------------------------------------------------------------------------------------
-def pml_profiles(n, npml, quibar=0.05):
-    """zeta at the nodes and at the staggered points of a dimension of n nodes (fdamp, cell 60)."""
+def pml_profiles(n, npml, quibar=0.05, low=True, high=True):
+    """zeta at the nodes and at the staggered points of a dimension of n nodes (fdamp, cell 60); `low` / `high`:
+    whether the dimension has a layer at its first / last nodes (the notebook has none at the top, cell 58)."""
     def zeta(pos):
-        a = np.where(pos <= npml, (npml - pos) / npml, np.where(pos >= n - 1 - npml, (pos - (n - 1 - npml)) / npml, 0.0))
+        a = np.zeros_like(pos)
+        if low:
+            a = np.where(pos <= npml, (npml - pos) / npml, a)
+        if high:
+            a = np.where(pos >= n - 1 - npml, (pos - (n - 1 - npml)) / npml, a)
         return quibar * (a - np.sin(2 * np.pi * a) / (2 * np.pi))
     i = np.arange(n, dtype=np.float64)
     return zeta(i), zeta(i + 0.5)
@@ -438,8 +443,15 @@ def _support_2d(coords, origin, spacing, shape, dtype):
 
 
 def pml_forward(vp_pad, spacing, origin_pad, space_order, dt, src_coords, wavelet, rec_coords, npml, quibar=0.05,
-                dtype=np.float32, return_last=False):
-    """Shot record (nt, nrec) of the Grote-Sim scheme on the padded grid vp_pad (km/s); fields zero outside."""
+                dtype=np.float32, return_last=False, sides=(True, True, True, True), edges="halo", vp_staggered=None):
+    """Shot record (nt, nrec) of the Grote-Sim scheme on the padded grid vp_pad (km/s).
+
+    Default: a layer on all four sides, fields zero outside the grid.  `sides` = (low x, high x, low z, high z)
+    selects the sides that have a layer.  edges="notebook" restates 03_pml.ipynb literally: the damped update and
+    the auxiliary fields only at the nodes of the layer regions (its subdomains d1-d3, cells 20-22, 76-81), the plain
+    wave equation elsewhere, and after the source term the boundary rows of cell 83 (u = 0 on the first and last x
+    node and on the last z node, u[x, 0] = u[x, 1]); `vp_staggered`: the velocity at the staggered points as the
+    caller's own array (the notebook's vel1, cells 26, 51-53) instead of the mean of c^2 over a cell's corners."""
     t = np.dtype(dtype).type
     vp = np.asarray(vp_pad, dtype=dtype)
     n1, n2 = vp.shape
@@ -450,8 +462,11 @@ def pml_forward(vp_pad, spacing, origin_pad, space_order, dt, src_coords, wavele
     cx = [t(w[k] / hx ** 2) for k in range(R + 1)]
     cz = [t(w[k] / hz ** 2) for k in range(R + 1)]
     m = (t(1) / (vp * vp)).astype(dtype)
-    zx0, zx1 = [a.astype(dtype) for a in pml_profiles(n1, npml, quibar)]
-    zz0, zz1 = [a.astype(dtype) for a in pml_profiles(n2, npml, quibar)]
+    zx0, zx1 = [a.astype(dtype) for a in pml_profiles(n1, npml, quibar, sides[0], sides[1])]
+    zz0, zz1 = [a.astype(dtype) for a in pml_profiles(n2, npml, quibar, sides[2], sides[3])]
+    notebook = edges == "notebook"
+    if notebook:   # staggered profiles: the last entry repeats the one before it (cells 72-74)
+        zx1[-1], zz1[-1] = zx1[-2], zz1[-2]
     ZX0, ZZ0 = zx0[:, None], zz0[None, :]
     ZX1, ZZ1 = zx1[:, None], zz1[None, :]
     # c^2 at the staggered points: mean of 1/m over the corners of the cell that lie inside the grid
@@ -462,6 +477,9 @@ def pml_forward(vp_pad, spacing, origin_pad, space_order, dt, src_coords, wavele
     acc[:, :-1] += inv[:, 1:]; cnt[:, :-1] += 1
     acc[:-1, :-1] += inv[1:, 1:]; cnt[:-1, :-1] += 1
     c2s = (acc / cnt).astype(dtype)
+    if vp_staggered is not None:
+        vs = np.asarray(vp_staggered, dtype=dtype)
+        c2s = (vs * vs).astype(dtype)
     H = R + 1
     def padz(a):
         return np.pad(a, H)
@@ -479,6 +497,13 @@ def pml_forward(vp_pad, spacing, origin_pad, space_order, dt, src_coords, wavele
     dt_, dt2 = t(dt), t(dt) * t(dt)
     half_s = (t(0.5) * (ZX0 + ZZ0) * dt_).astype(dtype)
     layer = (ZX1 != 0) | (ZZ1 != 0)
+    if notebook:   # the layer regions by node index (subdomains d1, d2, d3 and their mirror image at the top)
+        i1, i2 = np.arange(n1)[:, None], np.arange(n2)[None, :]
+        layer = np.zeros((n1, n2), dtype=bool)
+        if sides[0]: layer |= (i1 < npml) & (i2 >= 0)
+        if sides[1]: layer |= (i1 >= n1 - npml) & (i2 >= 0)
+        if sides[2]: layer |= (i2 < npml) & (i1 >= 0)
+        if sides[3]: layer |= (i2 >= n2 - npml) & (i1 >= 0)
     for time in range(1, nt - 1):
         cur, old, out = u[time % 3], u[(time + 2) % 3], u[(time + 1) % 3]
         f1, f2 = padz(p1[time & 1]), padz(p2[time & 1])
@@ -492,9 +517,16 @@ def pml_forward(vp_pad, spacing, origin_pad, space_order, dt, src_coords, wavele
         P2 = -t(0.5 / hz) * (sh(f2, -1, 0) + sh(f2, 0, 0) - sh(f2, -1, -1) - sh(f2, 0, -1))
         rhs = t(2) * cur - old * (t(1) - half_s) + dt2 * (lap / m - ZX0 * ZZ0 * cur - P1 - P2)
         out[...] = (rhs / (t(1) + half_s)).astype(dtype)
+        if notebook:
+            out[...] = np.where(layer, out, (t(2) * cur - old + dt2 * (lap / m)).astype(dtype))
         for p_, pts in enumerate(s_sup):                      # source into u[t+1] (cell 55)
             for i, j, wgt in pts:
                 out[i, j] += wgt * wav[time, p_] * dt2 / m[i, j]
+        if notebook:                                          # boundary rows, in the order of cell 83
+            out[0, :] = 0
+            out[n1 - 1, :] = 0
+            out[:, n2 - 1] = 0
+            out[:, 0] = out[:, 1]
         for p_, pts in enumerate(r_sup):                      # receivers sample u[t] (cell 56)
             rec[time, p_] = sum((wgt * cur[i, j] for i, j, wgt in pts), t(0))
         op, cq = padz(out), padz(cur)

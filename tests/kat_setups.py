@@ -126,3 +126,29 @@ def hankel_kat():
                          analytic_min=-5.322232e-03, analytic_max=+8.543911e-03,
                          rms_error=1.1265077536675204e-05,                            # cell 16 output
                          errors=printed_errors, rtol=0.05))
+
+
+def pml_notebook_kat():
+    """Inputs of seismic/abc_methods/03_pml.ipynb (cells 12-38, 42-43, 58-63): two layers of 1.5 and 2.5 km/s on
+    101 x 101 nodes at 10 m, a 20-node layer left, right and below (none at the top): 141 x 121 nodes from (-200, 0) m;
+    CFL 0.4 time step, 627 samples over 1 s; Ricker of 10 Hz at (500, 10) m, 141 receivers on the nodes of the row at
+    10 m; float64, space order 2.  Cell 96 asserts `np.isclose(np.linalg.norm(rec.data), 990, rtol=1)`."""
+    nx0, nz0, npml, h = 101, 101, 20, 10.0
+    n1, n2 = nx0 + 2 * npml, nz0 + npml
+    x0, x1, z0, z1 = -npml * h, 1000.0 + npml * h, 0.0, 1000.0 + npml * h
+    pzm = 50                                        # node of the interface, z = 500 m (cell 26)
+    v0 = np.empty((n1, n2))
+    v0[:, :pzm], v0[:, pzm:] = 1.5, 2.5
+    v1 = np.empty((n1, n2))                         # at the staggered points; last row / column repeat (cells 51-53)
+    v1[:, :pzm], v1[:, pzm:] = 1.5, 2.5
+    tn, cfl = 1000.0, 0.4
+    dtmax = h * cfl / v0.max()
+    ntmax = int(tn / dtmax) + 1
+    dt = tn / ntmax
+    nt = ntmax + 1                                  # samples of the time axis (cell 33)
+    rec = np.empty((n1, 2))
+    rec[:, 0] = np.linspace(x0, x1, n1)
+    rec[:, 1] = h
+    return dict(shape=(n1, n2), spacing=(h, h), origin=(x0, z0), vp=v0, vp_staggered=v1, npml=npml, quibar=0.05,
+                sides=(True, True, False, True), dt=dt, nt=nt, f0=0.01, src=np.array([[500.0, h]]), rec=rec,
+                space_order=2, kat=dict(norm_rec=990.0, rtol=1.0))

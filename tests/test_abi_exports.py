@@ -17,7 +17,7 @@ def test_library_exports_header_symbols():
     assert declared == set(mifwi.EXPORTED_SYMBOLS)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.mifwi_version() == 102
+    assert lib.mifwi_version() == 103
 
 
 def test_no_cpu_fallback():
