@@ -181,6 +181,8 @@ int launch_lap_scale(const Plan &p, const StepConsts<T> &k, const T *in, long in
         case 6: return launch_lap_r<T, 6>(p, k, in, in_shot_stride, power, out, out_shot_stride, nshots);
         case 7: return launch_lap_r<T, 7>(p, k, in, in_shot_stride, power, out, out_shot_stride, nshots);
         case 8: return launch_lap_r<T, 8>(p, k, in, in_shot_stride, power, out, out_shot_stride, nshots);
+        case 9: return launch_lap_r<T, 9>(p, k, in, in_shot_stride, power, out, out_shot_stride, nshots);
+        case 10: return launch_lap_r<T, 10>(p, k, in, in_shot_stride, power, out, out_shot_stride, nshots);
     }
     set_error("unsupported stencil radius");
     return MIFWI_EINVAL;
@@ -218,6 +220,8 @@ int launch_step_generic(const Plan &p, const StepConsts<T> &k, const StepPtrs<T>
         case 6: return launch_step_r<T, 6>(p, k, sp, gp, nshots);
         case 7: return launch_step_r<T, 7>(p, k, sp, gp, nshots);
         case 8: return launch_step_r<T, 8>(p, k, sp, gp, nshots);
+        case 9: return launch_step_r<T, 9>(p, k, sp, gp, nshots);
+        case 10: return launch_step_r<T, 10>(p, k, sp, gp, nshots);
     }
     set_error("unsupported stencil radius");
     return MIFWI_EINVAL;

@@ -70,7 +70,7 @@ template <typename T>
 static StepConsts<T> make_consts(const Plan &p)
 {
     StepConsts<T> k{};
-    double w[kMaxR + 1];
+    double w[kMaxRUntiled + 1];
     fd2_weights(p.L.R, w);
     double c0 = 0.0;
     for (int d = 0; d < p.cfg.ndim; ++d) {
@@ -476,8 +476,10 @@ static int build_sparse(Plan &p, SparseSet &S, const T *coords /* [tables][npoin
 static int validate(const mifwi_config &c)
 {
     if (c.ndim < 1 || c.ndim > 3) return fail(MIFWI_EINVAL, "ndim must be 1, 2 or 3");
-    if (c.space_order < 2 || c.space_order > 2 * kMaxR || (c.space_order & 1))
-        return fail(MIFWI_EINVAL, "space_order must be even and in 2..16");
+    if (c.space_order < 2 || c.space_order > 2 * kMaxRUntiled || (c.space_order & 1))
+        return fail(MIFWI_EINVAL, "space_order must be even and in 2..20");
+    if ((c.flags & MIFWI_FLAG_PML) && c.space_order > 2 * kMaxR)
+        return fail(MIFWI_EINVAL, "the perfectly matched layer is available up to space order 16");
     for (int d = 0; d < c.ndim; ++d) {
         if (c.shape[d] < 1) return fail(MIFWI_EINVAL, "shape entries must be positive");
         if (!(c.spacing[d] > 0.0)) return fail(MIFWI_EINVAL, "spacing entries must be positive");
@@ -530,7 +532,9 @@ static int create(const mifwi_config *cfg, mifwi_plan **out)
     // half-precision saved levels (its gradient stencils the saved level)
     // ... and with a free surface (the mirrored reads reach into laplace(u)/m as well: untiled kernels only)
     const bool ot4_untiled = (cfg->flags & MIFWI_FLAG_OT4) && ((cfg->flags & (MIFWI_FLAG_SAVE_F16 | MIFWI_FLAG_FREE_SURFACE)) || getenv("MIFWI_OT4_UNTILED"));
-    if (cfg->ndim == 2 && cfg->dtype == MIFWI_F32 && !(cfg->flags & (MIFWI_FLAG_GENERIC | MIFWI_FLAG_PML)) && !ot4_untiled) {
+    // (space orders 18 and 20 exist on the untiled kernels only)
+    const bool tiled_order = cfg->space_order <= 2 * kMaxR;
+    if (cfg->ndim == 2 && cfg->dtype == MIFWI_F32 && !(cfg->flags & (MIFWI_FLAG_GENERIC | MIFWI_FLAG_PML)) && !ot4_untiled && tiled_order) {
         // tiled fast path: pick the tile shape that wastes fewer threads on this grid
         const int n1 = p->L.n[1], n2 = p->L.n[2];
         auto waste = [&](int tx, int tz) { return (double)((n1 + tx - 1) / tx * tx) * ((n2 + tz - 1) / tz * tz); };
@@ -546,7 +550,7 @@ static int create(const mifwi_config *cfg, mifwi_plan **out)
         if (const char *env = getenv("MIFWI_PERSIST_SPIN")) p->persist_spin = atoi(env);   // tests: 0 abandons at once
         if (const char *env = getenv("MIFWI_PERSIST_NOCHECK")) p->persist_check = atoi(env) == 0;   // tests only
     }
-    if (cfg->ndim == 3 && cfg->dtype == MIFWI_F32 && !(cfg->flags & MIFWI_FLAG_GENERIC) && !ot4_untiled) {
+    if (cfg->ndim == 3 && cfg->dtype == MIFWI_F32 && !(cfg->flags & MIFWI_FLAG_GENERIC) && !ot4_untiled && tiled_order) {
         // 2.5-D fast path: 16 x 64 tiles of the (y, z) plane, x split into chunks so that one launch
         // offers several blocks per CU
         p->kind = 2;
@@ -2092,7 +2096,7 @@ static int tti_set_model(Plan &p, const void *eps, const void *delta, const void
 {
     if (int e = no_pml(p)) return e;
     if (p.cfg.ndim < 2) return fail(MIFWI_EINVAL, "TTI needs a 2-D or 3-D grid");
-    if (p.cfg.space_order % 4) return fail(MIFWI_EINVAL, "TTI needs space_order divisible by 4");
+    if (p.cfg.space_order % 4 || p.cfg.space_order > 2 * kMaxR) return fail(MIFWI_EINVAL, "TTI needs a space_order of 4, 8, 12 or 16");
     if (p.cfg.flags & (MIFWI_FLAG_FREE_SURFACE | MIFWI_FLAG_OT4))
         return fail(MIFWI_EINVAL, "TTI is not available with a free surface or the OT4 kernel");
     if (!eps || !delta || !theta) return fail(MIFWI_EINVAL, "epsilon, delta and theta are required");

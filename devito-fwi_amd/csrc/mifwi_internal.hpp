@@ -15,7 +15,8 @@
 
 namespace mifwi {
 
-constexpr int kMaxR = 8;        // space_order <= 16
+constexpr int kMaxR = 8;        // space_order <= 16 on the tiled, marching and TTI kernels
+constexpr int kMaxRUntiled = 10;   // space_order <= 20 on the untiled acoustic kernels (one thread per point)
 constexpr int kMaxCorners = 8;  // 2^ndim
 
 // ------------------------------------------------------------------------------------------
@@ -46,7 +47,7 @@ struct Layout {
 template <typename T>
 struct StepConsts {
     T c0;                  // w_0 * sum_d 1/h_d^2
-    T c[3][kMaxR + 1];     // c[d][k] = w_k / h_d^2, canonical dims
+    T c[3][kMaxRUntiled + 1];     // c[d][k] = w_k / h_d^2, canonical dims
     T dt, dt2, inv_dt2;
     int n0, n1, n2;
     long s0, s1, off0;

@@ -117,7 +117,7 @@ typedef struct mifwi_config {
     int32_t shape[3];      /* padded grid shape, shape[0..ndim)                            */
     double spacing[3];     /* grid spacing per dimension (m)                               */
     double origin[3];      /* coordinates of padded-grid point 0 (origin - nbl*spacing)    */
-    int32_t space_order;   /* even, 2..16                                                  */
+    int32_t space_order;   /* even, 2..16; 18 and 20 on the untiled kernels (any dtype)    */
     int32_t nt;            /* time samples; steps run time = 1 .. nt-2                     */
     double dt;             /* time step (ms)                                               */
     int32_t dtype;         /* MIFWI_F32 or MIFWI_F64: element type of every array argument */

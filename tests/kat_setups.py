@@ -152,3 +152,17 @@ def pml_notebook_kat():
     return dict(shape=(n1, n2), spacing=(h, h), origin=(x0, z0), vp=v0, vp_staggered=v1, npml=npml, quibar=0.05,
                 sides=(True, True, False, True), dt=dt, nt=nt, f0=0.01, src=np.array([[500.0, h]]), rec=rec,
                 space_order=2, kat=dict(norm_rec=990.0, rtol=1.0))
+
+
+def drp_notebook_kat():
+    """Inputs of the standard (Taylor-weight) run of seismic/tutorials/07_DRP_schemes.ipynb (cells 15-23): 201 x 201
+    nodes at 10 m, 1.5 km/s above node 121 in z and 4.0 km/s below, 10 absorbing nodes, space order 20, float32;
+    501 samples of 1 ms, Ricker of 15 Hz at (1000, 800) m, no receivers.  Cell 40 asserts
+    `np.isclose(np.linalg.norm(u.data[-1]), 139.108, atol=0, rtol=1e-4)`; with three circular time levels
+    `u.data[-1]` is the level of time index 500 (500 % 3 == 2), which the one further step the notebook's operator
+    takes (to time index 501, buffer 0) leaves as it was."""
+    shape, h = (201, 201), 10.0
+    v = np.empty(shape, dtype=np.float32)
+    v[:, :121], v[:, 121:] = 1.5, 4.0
+    return dict(shape=shape, spacing=(h, h), origin=(0.0, 0.0), nbl=10, space_order=20, vp=v, dt=1.0, t0=0.0, tn=500.0,
+                nt=501, f0=0.015, src=np.array([[1000.0, 800.0]]), kat=dict(norm_last=139.108, rtol=1e-4))

@@ -109,12 +109,18 @@ def test_multi_source_per_shot(mifwi):
     _check_case(mifwi, Case((40, 36), (10.0, 10.0), nbl=8, space_order=4, nt=110, nshots=2, nrec=9, nsrc=3, seed=11))
 
 
+@pytest.mark.parametrize("shape,so", [((44, 40), 18), ((44, 40), 20), ((26, 24, 28), 18), ((26, 24, 28), 20)])
+def test_space_orders_above_the_tiled_kernels(mifwi, shape, so):
+    """Space orders 18 and 20 (the reference's 07_DRP_schemes.ipynb runs at 20) take the untiled kernels."""
+    _check_case(mifwi, Case(shape, (10.0,) * len(shape), nbl=6, space_order=so, nt=70, nshots=2, nrec=7, seed=so))
+
+
 def test_error_paths(mifwi):
     case = Case((20, 20), (10.0, 10.0), nbl=4, space_order=4, nt=20, nshots=1, nrec=3)
     with pytest.raises(mifwi.MifwiError):
         mifwi.Plan((20, 20), (10., 10.), (0., 0.), 5, 20, 1.0, 1, 3)       # odd order
     with pytest.raises(mifwi.MifwiError):
-        mifwi.Plan((20, 20), (10., 10.), (0., 0.), 18, 20, 1.0, 1, 3)      # order too high
+        mifwi.Plan((20, 20), (10., 10.), (0., 0.), 22, 20, 1.0, 1, 3)      # order too high
     plan = mifwi.Plan(case.prob.shape_pad, case.prob.spacing, case.prob.origin_pad, 4, case.nt, case.dt, 1, 3)
     with pytest.raises(mifwi.MifwiError):
         plan.forward(case.wavelet, nshots=1)                               # no model yet

@@ -343,3 +343,37 @@ def test_kat_analytic_hankel_space_orders_through_solver_api():
         err = np.linalg.norm(r[:-1] / h ** 2 - a[:-1], 2) / np.sqrt(k["nt"] - 1)
         assert np.isclose(err, want, rtol=k["kat"]["rtol"]), (so, nn, err, want)
     engine.clear()
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_kat_drp_notebook_wavefield_norm_through_solver_api(dtype):
+    """07_DRP_schemes.ipynb cells 15-23 and 40 on the GPU: the standard run at space order 20 (the untiled kernels:
+    the tiled ones stop at 16), `np.isclose(np.linalg.norm(u.data[-1]), 139.108, atol=0, rtol=1e-4)` as the notebook
+    asserts it, and the same level against the CPU restatement."""
+    from mifwi import engine
+    from seismic import Model, AcquisitionGeometry
+    from seismic.acoustic import AcousticWaveSolver
+    from kat_setups import drp_notebook_kat
+    k = drp_notebook_kat()
+    model = Model(vp=k["vp"], origin=k["origin"], shape=k["shape"], spacing=k["spacing"], space_order=k["space_order"],
+                  nbl=k["nbl"], bcs="damp", dtype=dtype, dt=k["dt"])
+    geometry = AcquisitionGeometry(model, k["src"].copy(), k["src"], t0=k["t0"], tn=k["tn"], src_type='Ricker',
+                                   f0=k["f0"])
+    assert geometry.nt == k["nt"]
+    solver = AcousticWaveSolver(model, geometry, kernel='OT2', space_order=k["space_order"])
+    _, u, _ = solver.forward()
+    levels = np.asarray(u.data)
+    assert levels.shape[0] == 3
+    norm = float(np.linalg.norm(levels[-1]))
+    print("norm(u.data[-1]) = %.4f" % norm)
+    assert np.isclose(norm, k["kat"]["norm_last"], atol=0, rtol=k["kat"]["rtol"])
+    prob = orc.Problem(k["vp"].astype(dtype), k["spacing"], k["nbl"], k["space_order"], dtype=dtype, dt=k["dt"])
+    tv = np.linspace(k["t0"], k["tn"], k["nt"])
+    w = orc.ricker(k["f0"], tv).astype(dtype).reshape(k["nt"], 1)
+    want = prob.forward(k["src"], w, k["src"], dt=k["dt"], return_last=True)[-1][(k["nt"] - 1) % 3]
+    got = levels[-1]
+    assert got.shape == want.shape
+    err = np.linalg.norm(got - want) / np.linalg.norm(want)
+    print("level of time index %d against the restatement: %.2e" % (k["nt"] - 1, err))
+    assert err < (2e-5 if dtype == np.float32 else 1e-12)
+    engine.clear()

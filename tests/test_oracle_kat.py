@@ -12,7 +12,7 @@ import numpy as np
 import pytest
 
 from oracle import oracle as orc
-from kat_setups import circle_kat, circle_notebook_kat, hankel_kat, layers3d_kat
+from kat_setups import circle_kat, circle_notebook_kat, drp_notebook_kat, hankel_kat, layers3d_kat
 
 
 def test_fd_weights_match_sympy():
@@ -212,3 +212,16 @@ def test_kat_analytic_hankel_space_orders():
         r = _hankel_trace(k, (nn, nn), (h, h), so, np.float32)
         err = np.linalg.norm(r[:-1] / h ** 2 - a[:-1], 2) / np.sqrt(k["nt"] - 1)
         assert np.isclose(err, want, rtol=k["kat"]["rtol"]), (so, nn, err, want)
+
+
+def test_kat_drp_notebook_wavefield_norm():
+    """07_DRP_schemes.ipynb cell 40: the norm of the last wavefield of the standard space-order-20 run, 139.108 to
+    1e-4."""
+    k = drp_notebook_kat()
+    prob = orc.Problem(k["vp"], k["spacing"], k["nbl"], k["space_order"], dtype=np.float32, dt=k["dt"])
+    tv = np.linspace(k["t0"], k["tn"], k["nt"])
+    w = orc.ricker(k["f0"], tv).astype(np.float32).reshape(k["nt"], 1)
+    levels = prob.forward(k["src"], w, np.zeros((0, 2)), dt=k["dt"], return_last=True)[-1]
+    norm = float(np.linalg.norm(levels[(k["nt"] - 1) % 3]))
+    print("norm of the level of time index %d: %.4f" % (k["nt"] - 1, norm))
+    assert np.isclose(norm, k["kat"]["norm_last"], atol=0, rtol=k["kat"]["rtol"])
