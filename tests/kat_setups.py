@@ -166,3 +166,19 @@ def drp_notebook_kat():
     v[:, :121], v[:, 121:] = 1.5, 4.0
     return dict(shape=shape, spacing=(h, h), origin=(0.0, 0.0), nbl=10, space_order=20, vp=v, dt=1.0, t0=0.0, tn=500.0,
                 nt=501, f0=0.015, src=np.array([[1000.0, 800.0]]), kat=dict(norm_last=139.108, rtol=1e-4))
+
+
+def modelling_notebook_kat():
+    """Inputs of seismic/tutorials/01_modelling.ipynb (cells 5-20): 101 x 101 nodes at 10 m, 1.5 km/s above node 51
+    in z and 2.5 km/s below, 10 absorbing nodes, space order 2, float32; the model's own time step over 1 s, Ricker
+    of 10 Hz at (500, 20) m, 101 receivers at 20 m depth.  Cell 23 asserts
+    `np.isclose(np.linalg.norm(rec.data), 370, rtol=1)`, i.e. a norm in (0, 740]: the order of magnitude only.  The
+    notebook's operator records `u.forward`, one sample later than the solver's `u`; the norm does not see that."""
+    shape, h = (101, 101), 10.0
+    v = np.empty(shape, dtype=np.float32)
+    v[:, :51], v[:, 51:] = 1.5, 2.5
+    rec = np.empty((101, 2))
+    rec[:, 0] = np.linspace(0.0, 1000.0, 101)
+    rec[:, 1] = 20.0
+    return dict(shape=shape, spacing=(h, h), origin=(0.0, 0.0), nbl=10, space_order=2, vp=v, t0=0.0, tn=1000.0,
+                f0=0.010, src=np.array([[500.0, 20.0]]), rec=rec, kat=dict(norm_rec=370.0, rtol=1.0))

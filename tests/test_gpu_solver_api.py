@@ -377,3 +377,24 @@ def test_kat_drp_notebook_wavefield_norm_through_solver_api(dtype):
     print("level of time index %d against the restatement: %.2e" % (k["nt"] - 1, err))
     assert err < (2e-5 if dtype == np.float32 else 1e-12)
     engine.clear()
+
+
+def test_kat_modelling_notebook_record_norm_through_solver_api():
+    """01_modelling.ipynb cells 5-23 on the GPU (the tiled kernels, the time loop in one launch): the norm of the shot
+    record, which the notebook asserts as `np.isclose(np.linalg.norm(rec.data), 370, rtol=1)`; the value is 369.97,
+    checked to 1e-3."""
+    from mifwi import engine
+    from seismic import Model, AcquisitionGeometry
+    from seismic.acoustic import AcousticWaveSolver
+    from kat_setups import modelling_notebook_kat
+    k = modelling_notebook_kat()
+    model = Model(vp=k["vp"], origin=k["origin"], shape=k["shape"], spacing=k["spacing"], space_order=k["space_order"],
+                  nbl=k["nbl"], bcs="damp")
+    geometry = AcquisitionGeometry(model, k["rec"], k["src"], t0=k["t0"], tn=k["tn"], src_type='Ricker', f0=k["f0"])
+    solver = AcousticWaveSolver(model, geometry, kernel='OT2', space_order=k["space_order"])
+    rec, _, _ = solver.forward()
+    norm = float(np.linalg.norm(np.asarray(rec.data)))
+    print("norm(rec.data) = %.4f" % norm)
+    assert np.isclose(norm, k["kat"]["norm_rec"], rtol=k["kat"]["rtol"])
+    assert np.isclose(norm, k["kat"]["norm_rec"], rtol=1e-3)
+    engine.clear()

@@ -12,7 +12,7 @@ import numpy as np
 import pytest
 
 from oracle import oracle as orc
-from kat_setups import circle_kat, circle_notebook_kat, drp_notebook_kat, hankel_kat, layers3d_kat
+from kat_setups import circle_kat, circle_notebook_kat, drp_notebook_kat, hankel_kat, layers3d_kat, modelling_notebook_kat
 
 
 def test_fd_weights_match_sympy():
@@ -225,3 +225,18 @@ def test_kat_drp_notebook_wavefield_norm():
     norm = float(np.linalg.norm(levels[(k["nt"] - 1) % 3]))
     print("norm of the level of time index %d: %.4f" % (k["nt"] - 1, norm))
     assert np.isclose(norm, k["kat"]["norm_last"], atol=0, rtol=k["kat"]["rtol"])
+
+
+def test_kat_modelling_notebook_record_norm():
+    """01_modelling.ipynb cell 23: `np.isclose(np.linalg.norm(rec.data), 370, rtol=1)`.  The assertion only fixes the
+    order of magnitude; the restatement gives 369.97, so the 370 is the rounded value and is checked to 1e-3 here."""
+    k = modelling_notebook_kat()
+    prob = orc.Problem(k["vp"], k["spacing"], k["nbl"], k["space_order"], dtype=np.float32)
+    dt = prob.critical_dt
+    nt = int(np.ceil((k["tn"] - k["t0"] + dt) / dt))
+    tv = np.linspace(k["t0"], k["t0"] + dt * (nt - 1), nt)
+    w = orc.ricker(k["f0"], tv).astype(np.float32).reshape(nt, 1)
+    norm = float(np.linalg.norm(prob.forward(k["src"], w, k["rec"], dt=dt)[0]))
+    print("norm of the record: %.4f" % norm)
+    assert np.isclose(norm, k["kat"]["norm_rec"], rtol=k["kat"]["rtol"])
+    assert np.isclose(norm, k["kat"]["norm_rec"], rtol=1e-3)
