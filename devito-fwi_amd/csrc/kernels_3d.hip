@@ -3,11 +3,13 @@
 // Layout reminder: grid (x, y, z), z contiguous, zero halos of width R around every dimension.
 // A 256-thread block owns a TY x TZ tile of the (y, z) plane and marches along x over a chunk of
 // planes.  Each thread owns 4 consecutive z points of one y row:
-//   * x direction: a register queue of the 2R+1 planes around the current one (one aligned 16-byte
-//     load per thread and plane feeds it);
-//   * y and z directions: the current plane of the tile plus its halo ring is staged in LDS (the
-//     centre from the register queue, the ring with 16-byte loads that neighbouring tiles' blocks
-//     keep warm in L2) and read back with ds_read_b128: the z line once, 2R row neighbours.
+//   * y and z directions: the NEWEST plane of the own column (x + R when output plane x is finished) plus its
+//     halo ring is staged in LDS (the centre from the registers, the ring with 16-byte loads that the
+//     neighbouring tiles' blocks, which request the same plane for their own columns in the same
+//     iteration, keep warm in L2) and read back with ds_read_b128: the z line once, 2R row neighbours;
+//   * x direction: the R planes behind the staged one are gathered from registers into its sum, and its own
+//     values are scattered into the R sums still open (R + 1 planes of values + R + 1 sums in registers;
+//     one aligned 16-byte load per thread and plane feeds them).
 // LDS is double-buffered so that a plane costs one barrier, and the loads of plane i+1 are issued
 // before the arithmetic of plane i.  old / m / eta are read and the result is written with one
 // aligned 16-byte access each: 20 bytes per point and step of compulsory traffic.
@@ -312,16 +314,29 @@ __global__ __launch_bounds__(TY *TZ / V, (XMODE == 1 || XMODE == 2 || XMODE >= 4
     const int32_t *cptr = a.cell_ptr ? a.cell_ptr + ((long)inj_tab * a.nty * a.ntz + tile) * (a.n0 + 1) : nullptr;
     const bool any_inj = cptr ? (cptr[xa] < cptr[xb]) : false;   // block-uniform
 
-    // register queue: planes x-R .. x+R of the own column, plus plane x+R+1 in flight (qn)
-    float q[2 * R + 1][V], qn[V];
+    // The x part of a plane's sum is split around the plane that is being staged.  In the iteration of output plane
+    // x the plane STAGED in LDS is x + R, the newest one of the own column: its in-plane (y, z) part and the x
+    // terms of the R planes behind it (gathered from the own values kept in registers) open the sum of output
+    // x + R, and its own values are scattered into the R sums that are still open (outputs x .. x + R - 1); the
+    // sum of output x is complete then.  The ring of a plane is thereby requested in the same iteration in which
+    // the neighbouring tiles request that plane for their own columns, so that it is still in the XCD's L2
+    // (staging the OUTPUT plane asked for it R planes later, when it was gone again).  A chunk takes R iterations
+    // more: the first R only stage, the last R only finish.
+    // Registers: R + 1 planes of own values and R + 1 open sums instead of a queue of 2R + 1 planes.
+    constexpr int NP = V / 2;
+    float pq[R + 1][V], qn[V];   // own values of planes x .. x+R (pq[0]: the output plane, pq[R]: the staged one); x+R+1 in flight
+    vf2 pa[R + 1][NP];           // open sums of outputs x .. x+R
 #pragma unroll
-    for (int j = 0; j < 2 * R; ++j) {
-        bldv<V>(curB, (unsigned)(xa + j) * sbu, col_l, q[j + 1]);
-    }
-    bldv<V>(curB, (unsigned)(xa + 2 * R) * sbu, col_l, qn);
+    for (int j = 0; j < R; ++j) bldv<V>(curB, (unsigned)(xa + j) * sbu, col_l, pq[j + 1]);   // planes xa-R .. xa-1
+    bldv<V>(curB, (unsigned)(xa + R) * sbu, col_l, qn);                                       // plane xa
     float hv[NHT][4];
 #pragma unroll
     for (int i = 0; i < NHT; ++i) bldv<4>(curB, (unsigned)(xa + R) * sbu, h_glb[i], hv[i]);
+#pragma unroll
+    for (int j = 0; j <= R; ++j) {
+#pragma unroll
+        for (int p = 0; p < NP; ++p) pa[j][p] = vf2{0.f, 0.f};
+    }
 
     // The result of a plane is stored at the start of the NEXT plane, ahead of that plane's loads: a wait for a
     // load then never has a younger store in front of it (the compiler's waits let the youngest loads stay in
@@ -332,31 +347,40 @@ __global__ __launch_bounds__(TY *TZ / V, (XMODE == 1 || XMODE == 2 || XMODE >= 4
     unsigned soff_p = 0, col_p = kDead;
 
     int buf = 0;
-    for (int x = xa; x < xb; ++x) {
+    for (int x = xa - R; x < xb; ++x) {
+        const bool fin = x >= xa;        // output plane x is completed and written in this iteration
+        const bool stg = x + R < xb;     // plane x + R is staged: it is an output plane of this chunk
         bstv_stream<V>(outB, soff_p, col_p, res_p);
-        // advance the queue: plane x+R arrived during the previous plane, x+R+1 is requested now
+        col_p = kDead;
+        // advance: plane x+R arrived during the previous iteration, x+R+1 is requested now; the sums move up by one
 #pragma unroll
-        for (int j = 0; j < 2 * R; ++j) {
+        for (int j = 0; j < R; ++j) {
 #pragma unroll
-            for (int i = 0; i < V; ++i) q[j][i] = q[j + 1][i];
+            for (int i = 0; i < V; ++i) pq[j][i] = pq[j + 1][i];
+#pragma unroll
+            for (int p = 0; p < NP; ++p) pa[j][p] = pa[j + 1][p];
         }
 #pragma unroll
-        for (int i = 0; i < V; ++i) q[2 * R][i] = qn[i];
+        for (int i = 0; i < V; ++i) pq[R][i] = qn[i];
         if (x + 1 < xb) bldv<V>(curB, (unsigned)(x + 2 * R + 1) * sbu, col_l, qn);
+        float(&cl)[V] = pq[R];
+        float(&own)[V] = pq[0];
         // this plane's coefficients are only needed once the stencil sum is complete
         float mm[V], ee[V], oo[V];
-        bldv<V, kBufStream>(mB, (unsigned)x * sbu, col_l, mm);
 #pragma unroll
-        for (int i = 0; i < V; ++i) ee[i] = 0.f;
-        if (!(x >= ef_lo && x < ef_hi)) bldv<V, kBufStream>(eB, (unsigned)x * sbu, col_l, ee);
-        bldv<V, kBufStream>(oldB, (unsigned)x * sbu, col_l, oo);
+        for (int i = 0; i < V; ++i) mm[i] = ee[i] = oo[i] = 0.f;
+        if (fin) {
+            bldv<V, kBufStream>(mB, (unsigned)x * sbu, col_l, mm);
+            if (!(x >= ef_lo && x < ef_hi)) bldv<V, kBufStream>(eB, (unsigned)x * sbu, col_l, ee);
+            bldv<V, kBufStream>(oldB, (unsigned)x * sbu, col_l, oo);
+        }
         // fourth-order-in-time kernel (see Step2DArgs): the level itself when the stencilled field is z, and the
         // biharmonic term of the saved level in gradient launches (both block-uniform)
         float ptv[V], bhv[V];
 #pragma unroll
         for (int i = 0; i < V; ++i) ptv[i] = bhv[i] = 0.f;
-        if (OT4 && a.pt) bldv<V>(buf_of(reinterpret_cast<const char *>(a.pt + (long)shot * a.shot_stride)), (unsigned)x * sbu, col_l, ptv);
-        if (OT4 && GRAD && a.bih)
+        if (OT4 && a.pt && fin) bldv<V>(buf_of(reinterpret_cast<const char *>(a.pt + (long)shot * a.shot_stride)), (unsigned)x * sbu, col_l, ptv);
+        if (OT4 && GRAD && a.bih && fin)
             bldv<V, kBufStream>(buf_of(reinterpret_cast<const char *>(a.bih + (long)shot * a.g_shot_stride)), (unsigned)x * sbu, col_l, bhv);
 
         // accumulators and saved level(s) of this plane: issued with the coefficient loads, used last
@@ -365,6 +389,8 @@ __global__ __launch_bounds__(TY *TZ / V, (XMODE == 1 || XMODE == 2 || XMODE >= 4
         if (GRAD) {
 #pragma unroll
             for (int i = 0; i < V; ++i) u0[i] = up[i] = g[i] = il[i] = po[i] = 0.f;
+        }
+        if (GRAD && fin) {
             gradb = reinterpret_cast<char *>(a.grad + (long)shot * a.g_shot_stride) + (long)x * sb;
             illumb = a.illum ? reinterpret_cast<char *>(a.illum + (long)shot * a.g_shot_stride) + (long)x * sb : nullptr;
             if (a.save_scale) {   // half-precision saved levels (uniform branch)
@@ -386,16 +412,18 @@ __global__ __launch_bounds__(TY *TZ / V, (XMODE == 1 || XMODE == 2 || XMODE >= 4
             if (illumb) bldv<V, kBufStream>(buf_of(illumb - (long)x * sb), (unsigned)x * sbu, col_l, il);
         }
 
-        // stage plane x: centre from the queue, ring from the registers loaded one plane ago
+        // stage plane x + R: centre from the own column, ring from the registers loaded one plane ago
         float *L = lds[buf];
-        lds_stv<V>(&L[(ty + R) * P + RZ + V * tq], q[R]);
+        if (stg) {
+            lds_stv<V>(&L[(ty + R) * P + RZ + V * tq], cl);
 #pragma unroll
-        for (int i = 0; i < NHT; ++i)
-            if (tid + i * NT < NH) lds_stv<4>(&L[h_lds[i]], hv[i]);
+            for (int i = 0; i < NHT; ++i)
+                if (tid + i * NT < NH) lds_stv<4>(&L[h_lds[i]], hv[i]);
+        }
 
         // injected terms of the cells this tile owns in plane x (rare)
         int inj_beg = 0, inj_end = 0;
-        if (__builtin_expect(any_inj, 0)) {
+        if (__builtin_expect(any_inj && fin, 0)) {
             inj_beg = cptr[x];
             inj_end = cptr[x + 1];
             if (__builtin_expect(inj_beg < inj_end, 0)) {
@@ -403,22 +431,22 @@ __global__ __launch_bounds__(TY *TZ / V, (XMODE == 1 || XMODE == 2 || XMODE >= 4
                 for (int j = tid; j < TY * TZ; j += NT) acc[j] = 0.f;
                 __syncthreads();
                 const float *w = ra->winj + ((long)shot * ra->nt + ra->time) * ra->winj_stride;
-                const int32_t *cl = ra->cell_local + (long)(ra->inj_per_shot ? shot : 0) * ra->inj_kmax;
-                for (int j = inj_beg + tid; j < inj_end; j += NT) acc[cl[j]] = w[j];
+                const int32_t *cloc = ra->cell_local + (long)(ra->inj_per_shot ? shot : 0) * ra->inj_kmax;
+                for (int j = inj_beg + tid; j < inj_end; j += NT) acc[cloc[j]] = w[j];
             }
         }
-        __syncthreads();
+        if (stg || inj_beg < inj_end) __syncthreads();   // block-uniform
 
         // request the next plane's ring before the arithmetic
-        if (x + 1 < xb) {
+        if (x + R + 1 < xb) {
 #pragma unroll
-            for (int i = 0; i < NHT; ++i) bldv<4>(curB, (unsigned)(x + 1 + R) * sbu, h_glb[i], hv[i]);
+            for (int i = 0; i < NHT; ++i) bldv<4>(curB, (unsigned)(x + 1 + 2 * R) * sbu, h_glb[i], hv[i]);
         }
         float bn[V], bc[V], bo[V], bd[V];
         if (BORN) {
 #pragma unroll
             for (int i = 0; i < V; ++i) bn[i] = bc[i] = bo[i] = bd[i] = 0.f;
-            if (live) {
+            if (live && fin) {
                 const long bs = (long)shot * a.b_shot_stride * 4 + (long)x * sb;
                 ldv_stream<V>(reinterpret_cast<const char *>(a.b_un) + bs, col, bn);
                 ldv_stream<V>(reinterpret_cast<const char *>(a.b_uc) + bs, col, bc);
@@ -428,8 +456,8 @@ __global__ __launch_bounds__(TY *TZ / V, (XMODE == 1 || XMODE == 2 || XMODE >= 4
         }
         float res[V], uc[V];
 #pragma unroll
-        for (int i = 0; i < V; ++i) res[i] = uc[i] = 0.f;
-        if (live) {
+        for (int i = 0; i < V; ++i) res[i] = 0.f, uc[i] = own[i];
+        if (stg && live) {
             const float *ctr = &L[(ty + R) * P + RZ + V * tq];
             // The sums are formed for PAIRS of neighbouring outputs (packed two-float multiply-adds), and every
             // multiply-add gives both outputs of a pair the SAME coefficient: the z line is walked as pairs of
@@ -437,7 +465,6 @@ __global__ __launch_bounds__(TY *TZ / V, (XMODE == 1 || XMODE == 2 || XMODE >= 4
             // d = k - RZ - 2p.  (Broadcasting one value to a pair of outputs instead needs every ordered pair of
             // coefficients in scalar registers: about sixty of them at radius 8, most of them spilled and read
             // back for every plane.)  Values are folded into the sums as soon as they are read.
-            constexpr int NP = V / 2;
             vf2 lap2[NP];
             float line[V + 2 * RZ];
 #pragma unroll
@@ -461,9 +488,7 @@ __global__ __launch_bounds__(TY *TZ / V, (XMODE == 1 || XMODE == 2 || XMODE >= 4
                 }
             }
 #pragma unroll
-            for (int i = 0; i < V; ++i) uc[i] = line[RZ + i];
-#pragma unroll
-            for (int p = 0; p < NP; ++p) lap2[p] = __builtin_elementwise_fma(vf2{a.c0, a.c0}, vf2{uc[2 * p], uc[2 * p + 1]}, lap2[p]);
+            for (int p = 0; p < NP; ++p) lap2[p] = __builtin_elementwise_fma(vf2{a.c0, a.c0}, vf2{cl[2 * p], cl[2 * p + 1]}, lap2[p]);
 #pragma unroll
             for (int k = 1; k <= R; ++k) {
                 const float cyk = ISO ? a.cz[k] : a.cy[k];
@@ -475,19 +500,29 @@ __global__ __launch_bounds__(TY *TZ / V, (XMODE == 1 || XMODE == 2 || XMODE >= 4
 #pragma unroll
                 for (int p = 0; p < NP; ++p) lap2[p] = __builtin_elementwise_fma(vf2{cyk, cyk}, vf2{hi[2 * p], hi[2 * p + 1]}, lap2[p]);
             }
+            // x terms of the planes behind the staged one
 #pragma unroll
             for (int k = 1; k <= R; ++k) {
                 const float cxk = ISO ? a.cz[k] : a.cx[k];
 #pragma unroll
                 for (int p = 0; p < NP; ++p)
-                    lap2[p] = __builtin_elementwise_fma(vf2{cxk, cxk}, vf2{q[R - k][2 * p], q[R - k][2 * p + 1]}, lap2[p]);
-#pragma unroll
-                for (int p = 0; p < NP; ++p)
-                    lap2[p] = __builtin_elementwise_fma(vf2{cxk, cxk}, vf2{q[R + k][2 * p], q[R + k][2 * p + 1]}, lap2[p]);
+                    lap2[p] = __builtin_elementwise_fma(vf2{cxk, cxk}, vf2{pq[R - k][2 * p], pq[R - k][2 * p + 1]}, lap2[p]);
             }
+#pragma unroll
+            for (int p = 0; p < NP; ++p) pa[R][p] = lap2[p];
+        }
+        // the staged plane's own values are the x term at distance k of the output k planes behind it
+#pragma unroll
+        for (int k = 1; k <= R; ++k) {
+            const float cxk = ISO ? a.cz[k] : a.cx[k];
+#pragma unroll
+            for (int p = 0; p < NP; ++p)
+                pa[R - k][p] = __builtin_elementwise_fma(vf2{cxk, cxk}, vf2{cl[2 * p], cl[2 * p + 1]}, pa[R - k][p]);
+        }
+        if (fin && live) {
             float lap[V];
 #pragma unroll
-            for (int i = 0; i < V; ++i) lap[i] = lap2[i / 2][i % 2];
+            for (int i = 0; i < V; ++i) lap[i] = pa[0][i / 2][i % 2];
             if (OT4 && a.pt) {   // the stencilled field was z; the pointwise terms take the level itself
 #pragma unroll
                 for (int i = 0; i < V; ++i) uc[i] = ptv[i];
@@ -542,12 +577,12 @@ __global__ __launch_bounds__(TY *TZ / V, (XMODE == 1 || XMODE == 2 || XMODE >= 4
         }
         // results: one V-point store per thread (dropped for lanes outside the grid); a thread that straddles
         // the end of a row stores its points one by one
-        const bool ragged = !full && nlive > 0;
+        const bool ragged = fin && !full && nlive > 0;
 #pragma unroll
         for (int i = 0; i < V; ++i) res_p[i] = res[i];
-        soff_p = (unsigned)x * sbu, col_p = col_s;
+        soff_p = fin ? (unsigned)x * sbu : 0u, col_p = fin ? col_s : kDead;
         if (__builtin_expect(ragged, 0)) bstv_ragged<V>(outB, (unsigned)x * sbu, col, res, nlive);
-        if (MODE == 3 && live) {
+        if (MODE == 3 && live && fin) {
             // half-precision copy of the new level into the saved array
             const float sc = a.save_scale[shot];
             char *cb = reinterpret_cast<char *>(a.copy16) + (((long)shot * a.copy_shot_stride * 4 + (long)x * sb) >> 1);
@@ -559,7 +594,7 @@ __global__ __launch_bounds__(TY *TZ / V, (XMODE == 1 || XMODE == 2 || XMODE >= 4
                     if (z + i < a.n2) ch[i] = __float2half_rn(fminf(fmaxf(res[i] * sc, -65504.0f), 65504.0f));
             }
         }
-        if (__builtin_expect(fs_rows && live, 0)) {
+        if (__builtin_expect(fs_rows && live && fin, 0)) {
             // free surface: antisymmetric mirror of rows 1..R into the z halo (see kernels_tiled2d.hip)
 #pragma unroll
             for (int i = 0; i < V; ++i) {
@@ -568,7 +603,7 @@ __global__ __launch_bounds__(TY *TZ / V, (XMODE == 1 || XMODE == 2 || XMODE >= 4
                     raw_buffer_store_f1(-res[i], outB, (int)(col - 4u * (unsigned)(z + zi)), (int)((unsigned)x * sbu), 0);
             }
         }
-        if (GRAD) {
+        if (GRAD && fin) {
             bstv_stream<V>(buf_of(gradb - (long)x * sb), (unsigned)x * sbu, col_s, g);
             if (illumb) bstv_stream<V>(buf_of(illumb - (long)x * sb), (unsigned)x * sbu, col_s, il);
             if (__builtin_expect(ragged, 0)) {
@@ -693,10 +728,8 @@ static int launch_r3(const Plan &p, const Step3DArgs &a, hipStream_t stream)
     // equal spacing in all three dimensions: one coefficient set instead of three (fewer SGPRs)
     bool iso = true;
     for (int k = 0; k <= R; ++k) iso = iso && a.cx[k] == a.cz[k] && a.cy[k] == a.cz[k];
-    // four points per thread (256 threads) by default; two points per thread (512 threads, twice the
-    // waves at half the registers) measured slower at every order and is kept for experiments
-    const bool two = (p.vec3d == 2);
-    if (two) return iso ? launch_r3v<R, 16, 2, true>(p, a, stream) : launch_r3v<R, 16, 2, false>(p, a, stream);
+    // four points per thread (256 threads); two points per thread (512 threads, twice the waves at half the
+    // registers) measured slower at every order
     return iso ? launch_r3v<R, 16, 4, true>(p, a, stream) : launch_r3v<R, 16, 4, false>(p, a, stream);
 }
 

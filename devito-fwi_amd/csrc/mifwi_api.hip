@@ -554,7 +554,6 @@ static int create(const mifwi_config *cfg, mifwi_plan **out)
         // 2.5-D fast path: 16 x 64 tiles of the (y, z) plane, x split into chunks so that one launch
         // offers several blocks per CU
         p->kind = 2;
-        if (const char *env = getenv("MIFWI_3D_VEC")) p->vec3d = atoi(env);  // tuning experiments
         p->tile_tx = 16, p->tile_tz = 64;
         p->ntx = (p->L.n[1] + p->tile_tx - 1) / p->tile_tx;
         p->ntz = (p->L.n[2] + 63) / 64;

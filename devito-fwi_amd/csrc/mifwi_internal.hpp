@@ -180,7 +180,6 @@ struct Plan {
     int slab_w = 0, slab_chunks = 1;   // two-step sweeps of the 2.5-D kernel: planes per slab (0 = off), chunks per slab
     unsigned char *eta_zero = nullptr;  // 2.5-D kernel: [tile][n0] flags of sponge-free patches (scratch of the next)
     int *eta_free = nullptr;            // 2.5-D kernel: [tile][2] longest run lo <= x < hi of sponge-free planes
-    int vec3d = 0;  // points per thread of the 2.5-D kernel: 0 = by stencil radius, else 2 or 4
     int vec2d = 4;      // points per thread of the tiled 2-D kernel (2: experiment, 32 x 32 tiles only)
     int pair_save = 1;  // saving forward loops of the tiled 2-D kernel write two saved levels every second step
     int pair_grad = 1;  // gradient loops update the accumulators every second step (tiled kernels)
