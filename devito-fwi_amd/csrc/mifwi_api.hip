@@ -1247,7 +1247,7 @@ static int prepare_save(Plan &p)
     const bool want_f16 = (p.cfg.flags & MIFWI_FLAG_SAVE_F16) && std::is_same<T, float>::value && p.kind != 0;
     const size_t slevel = want_f16 ? level / 2 : level;
     int rc;
-    if (!force && (double)slevel * nt <= 0.85 * (double)free_b) {
+    if (!force && (double)slevel * nt <= 0.92 * (double)free_b) {
         p.ck_K = 0;
         p.save_f16 = want_f16;
         if (want_f16 && !p.d_save_scale &&
@@ -1262,7 +1262,7 @@ static int prepare_save(Plan &p)
     // (nt - nc) stored + 2 per segment + ck_K + 2 for the segment being recomputed.  Of all (nc, K) that fit,
     // the smallest nc wins: only those steps are propagated a second time.  The tiled 2-D kernel and a forced
     // MIFWI_FLAG_CHECKPOINT checkpoint everything.
-    const double budget = 0.90 * (double)free_b / (double)level;
+    const double budget = 0.95 * (double)free_b / (double)level;
     const bool all = force || p.kind == 1;
     int best_nc = -1, best_K = 0;
     for (int K = 2; !all && K <= nsteps; K += 2) {
