@@ -176,7 +176,7 @@ struct Plan {
     int tile_tx = 0, tile_tz = 0, ntx = 0, ntz = 0;
     int xchunk = 0, nchunk = 0;
     int ncu = 256, bpc_fwd = 2, bpc_grad = 2;  // CUs and resident 2.5-D blocks per CU (plain / gradient)
-    int nchunk_env = 0;
+    int nchunk_env = 0, nchunk_grad_env = 0;
     int slab_w = 0, slab_chunks = 1;   // two-step sweeps of the 2.5-D kernel: planes per slab (0 = off), chunks per slab
     unsigned char *eta_zero = nullptr;  // 2.5-D kernel: [tile][n0] flags of sponge-free patches (scratch of the next)
     int *eta_free = nullptr;            // 2.5-D kernel: [tile][2] longest run lo <= x < hi of sponge-free planes
