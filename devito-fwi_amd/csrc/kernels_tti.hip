@@ -1387,6 +1387,7 @@ int launch_tti3d_weights(const Plan &p)
 // chunks of planes per tile: about `rounds` blocks per CU, chunks no shorter than twice the planes a chunk primes
 static void tti3d_chunks(const Plan &p, int tiles, int planes, int prime, int rounds, int &nchunk, int &xchunk)
 {
+    if (const char *env = getenv("MIFWI_TTI3D_ROUNDS")) rounds = std::max(1, atoi(env));   // tuning experiments
     int n = (rounds * p.ncu + tiles - 1) / tiles;
     n = std::max(1, std::min(n, planes / (2 * prime)));
     xchunk = (planes + n - 1) / n;
