@@ -166,6 +166,23 @@ def cpu_baseline(true_model, init_model, src, rec, wavelet, dt, space_order, nsh
     return out
 
 
+class _env(object):
+    """An environment variable set for the creation of a plan (the library reads its switches there)."""
+
+    def __init__(self, name, value):
+        self.name, self.value = name, value
+
+    def __enter__(self):
+        self.old = os.environ.get(self.name)
+        os.environ[self.name] = self.value
+
+    def __exit__(self, *exc):
+        if self.old is None:
+            os.environ.pop(self.name, None)
+        else:
+            os.environ[self.name] = self.old
+
+
 def roofline_3d(mifwi, device, space_order=16, n=512, nbl=40, nt=14):
     """Forward time step of the 2.5-D kernel on the synthetic 3-D stress grid (512^3 + sponge = 592^3,
     one shot): algorithmic 20 B per point update / kernel duration (HIP events around the time loop
@@ -183,8 +200,11 @@ def roofline_3d(mifwi, device, space_order=16, n=512, nbl=40, nt=14):
     g = np.linspace(0, (n - 1) * 10.0, 64, dtype=np.float32)
     rec = np.stack(np.meshgrid(g, g, indexing="ij"), -1).reshape(-1, 2)
     rec = np.concatenate([rec, np.full((rec.shape[0], 1), 20.0, np.float32)], 1)
-    plan = mifwi.Plan(sp, model.spacing, model.grid.origin, space_order, nt, dt, 1, rec.shape[0], max_shots=1,
-                      device=device)
+    # every plane computed: a forward loop otherwise only writes the planes the wave has not reached, which after
+    # these few steps is most of the grid
+    with _env("MIFWI_3D_BOX", "0"):
+        plan = mifwi.Plan(sp, model.spacing, model.grid.origin, space_order, nt, dt, 1, rec.shape[0], max_shots=1,
+                          device=device)
     plan.set_model(model.vp.data, model.damp.data)
     plan.set_geometry(src, rec)
     t = np.arange(nt) * dt
@@ -279,11 +299,14 @@ def c4_leg(mifwi, device, space_order=8, n=512, nbl=40, nt=500):
     out, grad_f32 = None, None
     # the float32 default first; then the same evaluation with the saved levels in half precision
     # (MIFWI_FLAG_SAVE_F16: every level fits, nothing is propagated twice; the gradient differs in the 5th digit)
-    for flags in (0, mifwi.FLAG_SAVE_F16):
-        plan = mifwi.Plan(sp, model.spacing, model.grid.origin, space_order, nt, dt, 1, rec.shape[0], max_shots=1,
-                          device=device, flags=flags)
+    # and in between the float32 evaluation with every plane of every forward step computed (MIFWI_3D_BOX=0): by
+    # default forward loops only write the x planes the wave has not reached yet, which are exactly zero
+    for flags, box in ((0, "1"), (0, "0"), (mifwi.FLAG_SAVE_F16, "1")):
+        with _env("MIFWI_3D_BOX", box):
+            plan = mifwi.Plan(sp, model.spacing, model.grid.origin, space_order, nt, dt, 1, rec.shape[0], max_shots=1,
+                              device=device, flags=flags)
         plan.set_geometry(src, rec)
-        if flags == 0:
+        if flags == 0 and box == "1":
             plan.set_model(model.vp.data, model.damp.data)
             plan.forward(wav, rec_out=obs)
         plan.set_model(model0.vp.data, model0.damp.data)
@@ -301,13 +324,18 @@ def c4_leg(mifwi, device, space_order=8, n=512, nbl=40, nt=500):
         leg = {"gpoints_per_s": pts / walls[1] / 1e9, "wall_ms": walls[1] * 1e3, "first_call_wall_ms": walls[0] * 1e3,
                "forward_loop_ms": st["fwd_ms"], "gradient_loop_ms_incl_recomputation": st["bwd_ms"],
                "checkpointed_steps": st["ckpt_steps"], "device_bytes": st["device_bytes"], "objective": objective}
-        if flags == 0:
+        if flags == 0 and box == "1":
             out = dict({"workload": "synthetic 3-D %d^3 (+nbl %d = %d^3), space_order=%d, nt=%d, 1 shot: forward + L2 "
                                     "gradient; the first %d steps checkpointed in segments of %d and propagated twice, "
-                                    "the levels of the other %d stored" %
+                                    "the levels of the other %d stored; forward steps write the x planes the wave has "
+                                    "not reached (exact zeros) without computing them" %
                                     (n, nbl, sp[0], space_order, nt, st["ckpt_steps"], st["ckpt_segment"],
                                      nt - 2 - st["ckpt_steps"])}, **leg)
             grad_f32 = grad
+        elif flags == 0:
+            leg["gradient_equal_to_default"] = bool(torch.equal(grad, grad_f32))
+            leg["what"] = "same evaluation with every plane of every forward step computed (MIFWI_3D_BOX=0)"
+            out["every_plane_computed"] = leg
         else:
             num = float(torch.linalg.vector_norm((grad - grad_f32).double()))
             den = float(torch.linalg.vector_norm(grad_f32.double()))

@@ -258,8 +258,8 @@ __global__ __launch_bounds__(TY *TZ / V, (XMODE == 1 || XMODE == 2 || XMODE >= 4
     const int chunk = t % a.nchunk;
     const int shot = t / a.nchunk;
     const int tile = tile_y * a.ntz + tile_z;
-    const int xa = a.x_lo + chunk * a.xchunk;
-    const int xb = min(a.x_hi, xa + a.xchunk);
+    const int oa = a.x_lo + chunk * a.xchunk;   // this block's share of the planes of the launch
+    const int ob = min(a.x_hi, oa + a.xchunk);
     const int y0 = tile_y * TY, z0 = tile_z * TZ;
 
     const int ty = tid / TQ, tq = tid - ty * TQ;
@@ -305,6 +305,43 @@ __global__ __launch_bounds__(TY *TZ / V, (XMODE == 1 || XMODE == 2 || XMODE >= 4
         h_lds[i] = row * P + 4 * c4;
         h_glb[i] = h_ok[i] ? (unsigned)((a.off0 + (long)gy * a.s1 + (z0 - RZ + 4 * c4)) * 4) : kDead;
     }
+
+    // Forward loops keep, per shot, the range of planes in which any of their steps so far has produced a value other
+    // than zero (a.box_lo / a.box_hi, updated below).  R planes further out the two levels this step reads are still
+    // exactly zero and so is its result, unless something is injected there: those planes are written, not computed,
+    // and the planes that can hold something are shared out anew among the chunks.  (A range read while other blocks
+    // of the launch widen it is a wider one: still correct.)
+    constexpr bool BOX = (XMODE == 0 || XMODE == 3);
+    int xa = oa, xb = ob;
+    if (BOX && a.box_lo) {
+        int lo = min(a.box_lo[shot] - R, a.inj_xlo), hi = max(a.box_hi[shot] + R, a.inj_xhi);
+        lo = max(lo, a.x_lo), hi = min(hi, a.x_hi);
+        if (hi < lo) hi = lo;
+        const int xc = (hi - lo + a.nchunk - 1) / a.nchunk;
+        xa = min(hi, lo + chunk * xc), xb = min(hi, xa + xc);
+        const float zero[V] = {};
+        const bool ragged0 = !full && nlive > 0;
+        for (int x = oa; x < ob; ++x) {
+            if (x >= lo && x < hi) {
+                x = hi - 1;
+                continue;
+            }
+            bstv_stream<V>(outB, (unsigned)x * sbu, col_s, zero);
+            if (__builtin_expect(ragged0, 0)) bstv_ragged<V>(outB, (unsigned)x * sbu, col, zero, nlive);
+            if (MODE == 3 && live) {
+                char *cb = reinterpret_cast<char *>(a.copy16) + (((long)shot * a.copy_shot_stride * 4 + (long)x * sb) >> 1);
+                if (full) {
+                    stv_half_stream<V>(cb, col, zero, 1.0f);
+                } else {
+                    __half *ch = reinterpret_cast<__half *>(cb + (col >> 1));
+                    for (int i = 0; i < V; ++i)
+                        if (z + i < a.n2) ch[i] = __float2half_rn(0.0f);
+                }
+            }
+        }
+        if (xa >= xb) return;   // (block-uniform)
+    }
+    int nz_lo = 0x7fffffff, nz_hi = -0x7fffffff;   // planes in which this thread has produced a nonzero value
 
     // planes ef_lo <= x < ef_hi of this tile are free of the sponge: they skip its 4 bytes per point
     const int ef_lo = a.eta_free ? a.eta_free[2 * tile] : 0, ef_hi = a.eta_free ? a.eta_free[2 * tile + 1] : 0;
@@ -575,6 +612,13 @@ __global__ __launch_bounds__(TY *TZ / V, (XMODE == 1 || XMODE == 2 || XMODE >= 4
                 }
             }
         }
+        if (BOX && a.box_lo && fin) {
+            unsigned bits = 0;
+#pragma unroll
+            for (int i = 0; i < V; ++i)
+                if (i < nlive) bits |= __float_as_uint(res[i]);
+            if (bits << 1) nz_lo = min(nz_lo, x), nz_hi = max(nz_hi, x + 1);
+        }
         // results: one V-point store per thread (dropped for lanes outside the grid); a thread that straddles
         // the end of a row stores its points one by one
         const bool ragged = fin && !full && nlive > 0;
@@ -615,6 +659,17 @@ __global__ __launch_bounds__(TY *TZ / V, (XMODE == 1 || XMODE == 2 || XMODE >= 4
         buf ^= 1;
     }
     bstv_stream<V>(outB, soff_p, col_p, res_p);
+    if (BOX && a.box_lo) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            nz_lo = min(nz_lo, __shfl_xor(nz_lo, o));
+            nz_hi = max(nz_hi, __shfl_xor(nz_hi, o));
+        }
+        if ((tid & 63) == 0 && nz_lo < nz_hi) {
+            atomicMin(&a.box_lo[shot], nz_lo);
+            atomicMax(&a.box_hi[shot], nz_hi);
+        }
+    }
 }
 
 // eta_zero[tile][x] = 1 when the sponge field vanishes on the whole (tile, plane) patch

@@ -153,6 +153,8 @@ static void destroy(Plan *p)
     dev_free(p->rot_v);
     dev_free(p->saved);
     dev_free(p->ckpt);
+    dev_free(p->d_box);
+    dev_free(p->d_ck_box);
     dev_free(p->seg);
     free_sparse(p->src);
     free_sparse(p->rec);
@@ -301,6 +303,7 @@ static int build_sparse(Plan &p, SparseSet &S, const T *coords /* [tables][npoin
     };
     std::vector<Entry> ent;
     S.max_count = 0;
+    S.x_lo = 0x7fffffff, S.x_hi = -0x7fffffff;
     for (int t = 0; t < tables; ++t) {
         ent.clear();
         for (int q = 0; q < npoint; ++q) {
@@ -365,6 +368,7 @@ static int build_sparse(Plan &p, SparseSet &S, const T *coords /* [tables][npoin
                 const long r1 = rel - (long)i0 * L.s0;
                 const int i1 = (int)(r1 / L.s1), i2 = (int)(r1 % L.s1);
                 cs[u] = C3{(i1 / p.tile_tx) * p.ntz + (i2 / p.tile_tz), i0, (i1 % p.tile_tx) * p.tile_tz + (i2 % p.tile_tz), u};
+                S.x_lo = std::min(S.x_lo, i0), S.x_hi = std::max(S.x_hi, i0 + 1);
             }
             std::sort(cs.begin(), cs.end(), [](const C3 &a, const C3 &b) {
                 if (a.tile != b.tile) return a.tile < b.tile;
@@ -561,6 +565,10 @@ static int create(const mifwi_config *cfg, mifwi_plan **out)
         if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) p->ncu = prop.multiProcessorCount;
         p->bpc_fwd = step3d_blocks_per_cu(p->L.R, false);
         p->bpc_grad = step3d_blocks_per_cu(p->L.R, true);
+        // forward loops skip the planes the wave has not reached (see Step3DArgs::box_lo); not with the mirror rows of a
+        // free surface, which live outside the planes' own rows
+        p->box_enabled = !(cfg->flags & (MIFWI_FLAG_FREE_SURFACE | MIFWI_FLAG_OT4));
+        if (const char *env = getenv("MIFWI_3D_BOX")) p->box_enabled = p->box_enabled && atoi(env) != 0;
         if (const char *env = getenv("MIFWI_3D_NCHUNK")) p->nchunk_env = std::max(1, atoi(env));  // tuning experiments
         if (const char *env = getenv("MIFWI_3D_NCHUNK_GRAD")) p->nchunk_grad_env = std::max(1, atoi(env));
         if ((cfg->flags & MIFWI_FLAG_TIME_BLOCK) && !(cfg->flags & MIFWI_FLAG_OT4)) p->slab_w = 64, p->slab_chunks = 2;   // the best measured at 592^3
@@ -1041,6 +1049,10 @@ static int forward_step(Plan &p, const LoopCtx<T> &c, const T *cur, const T *old
         }
         if (inject) set_inject3(a, p.src, p);
         if (interp) set_interp3(a, p.rec, p.d_rec);
+        if (p.box_active && inject && !born && x_lo < 0) {
+            a.box_lo = p.d_box, a.box_hi = p.d_box + p.cfg.max_shots;
+            a.inj_xlo = a.cell_ptr ? p.src.x_lo : 0x7fffffff, a.inj_xhi = a.cell_ptr ? p.src.x_hi : -0x7fffffff;
+        }
         a.cur = (const float *)cur, a.old = (const float *)old, a.out = (float *)out, a.time = time;
         if ((rc = ot4_prestep(p, c.a3, a, launches))) return rc;
         if (copy) {
@@ -1475,8 +1487,18 @@ static int run_forward(Plan &p, int nshots, int save)
         }
         return MIFWI_OK;
     };
+    // planes the wave has not reached are written, not computed (2.5-D kernel, one step per launch)
+    const bool box = p.kind == 2 && p.box_enabled && slab_w == 0;
+    if (box && !p.d_box && (rc = dev_alloc(p, (void **)&p.d_box, 2 * (size_t)p.cfg.max_shots * sizeof(int), true))) return rc;
+    if (box && ckpt && !p.d_ck_box &&
+        (rc = dev_alloc(p, (void **)&p.d_ck_box, 2 * (size_t)p.cfg.max_shots * p.ck_nseg * sizeof(int), true)))
+        return rc;
     auto enqueue = [&](int &launches) -> int {
         if (slab_w > 0) return enqueue_slabs(launches);
+        if (box) {   // empty range: lo = 0x7f7f7f7f, hi = 0x80808080 (negative)
+            MIFWI_HIP(hipMemsetAsync(p.d_box, 0x7f, (size_t)p.cfg.max_shots * sizeof(int), p.stream));
+            MIFWI_HIP(hipMemsetAsync(p.d_box + p.cfg.max_shots, 0x80, (size_t)p.cfg.max_shots * sizeof(int), p.stream));
+        }
         for (int time = 1; time <= nt - 2; ++time) {
             if (ckpt && time <= p.ck_nc && (time - 1) % p.ck_K == 0) {
                 // keep the two levels that enter this segment: u[time-1], u[time]
@@ -1486,6 +1508,9 @@ static int run_forward(Plan &p, int nshots, int save)
                 int r;
                 if ((r = copy_levels<T>(p, dst, cstride, lvl(time - 1), shot_stride, 1, nshots))) return r;
                 if ((r = copy_levels<T>(p, dst + L.field, cstride, lvl(time), shot_stride, 1, nshots))) return r;
+                if (box)   // and the range the two levels lie in
+                    MIFWI_HIP(hipMemcpyAsync(p.d_ck_box + (size_t)j * 2 * p.cfg.max_shots, p.d_box,
+                                             2 * (size_t)p.cfg.max_shots * sizeof(int), hipMemcpyDeviceToDevice, p.stream));
             }
             if (mixed && time > p.ck_nc) {
                 int r;
@@ -1515,6 +1540,11 @@ static int run_forward(Plan &p, int nshots, int save)
     int launches = 0;
     float ms = 0;
     const auto key = std::make_tuple(0, nshots, save ? 1 : 0, slab_w, 0);
+    struct BoxScope {   // forward_step hands the range to the kernel while this loop is being enqueued
+        Plan &p;
+        BoxScope(Plan &q, bool on) : p(q) { p.box_active = on; }
+        ~BoxScope() { p.box_active = false; }
+    } box_scope(p, box);
     if (!ckpt && !in_saved && persist_eligible(p, nshots, &p.rec, false)) {
         auto whole_loop = [&](int &n) -> int { return enqueue_persist(p, nshots, true, false, false, copy_save, n); };
         if ((rc = timed_loop(p, nullptr, whole_loop, launches, ms))) return rc;
@@ -1631,11 +1661,19 @@ static int run_backward(Plan &p, int nshots, bool with_grad, bool with_illum)
             // seg level i holds u[t0 - 1 + i]
             if ((r = copy_levels<T>(p, seg, seg_stride, (const T *)p.ckpt + (long)j * 2 * L.field, cstride, 2, nshots)))
                 return r;
+            const bool box = p.kind == 2 && p.box_enabled && p.d_box && p.d_ck_box;
+            if (box)   // the range the checkpointed levels lie in
+                MIFWI_HIP(hipMemcpyAsync(p.d_box, p.d_ck_box + (size_t)j * 2 * p.cfg.max_shots,
+                                         2 * (size_t)p.cfg.max_shots * sizeof(int), hipMemcpyDeviceToDevice, p.stream));
+            p.box_active = box;
             for (int time = t0; time <= t1; ++time) {
                 T *c = seg + (long)(time - t0 + 1) * L.field;
-                if ((r = forward_step<T>(p, fctx, c, c - L.field, c + L.field, seg_stride, time, false, launches)))
+                if ((r = forward_step<T>(p, fctx, c, c - L.field, c + L.field, seg_stride, time, false, launches))) {
+                    p.box_active = false;
                     return r;
+                }
             }
+            p.box_active = false;
             for (int time = t1; time >= t0; --time) {
                 const T *u0 = seg + (long)(time - t0 + 1) * L.field;
                 const int role = pair_role(time);

@@ -1,0 +1,103 @@
+"""Forward loops of the 2.5-D kernel write, without computing them, the x planes the wave has not reached yet (the
+library keeps the range of planes that hold a value other than zero and widens it by the stencil radius per step).
+The result must be the one of the full sweep, value for value: `MIFWI_3D_BOX=0` switches the skipping off.
+The reference has no counterpart (Devito sweeps the whole grid every step); parity of the 3-D kernels with the CPU
+restatement is tested in test_gpu_parity_abi.py and test_gpu_golden.py with the skipping on."""
+import numpy as np
+import pytest
+
+from helpers import Case, smooth_random_vp
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def mifwi():
+    import mifwi as m
+    return m
+
+
+def _long_case(scale=1.0, nt=44, seed=5):
+    """A grid long in x with the sources at 20 % and 70 % of its length: 44 steps do not take the wave to the ends."""
+    shape = (150, 22, 34)
+    vp = (smooth_random_vp(shape, seed=seed) * scale).astype(np.float32)
+    c = Case(shape, (10.0, 10.0, 10.0), nbl=5, space_order=8, nt=nt, nshots=2, nrec=13, seed=seed, vp=vp)
+    dom = np.array([(n - 1) * 10.0 for n in shape], dtype=np.float32)
+    c.src[0, 0, :] = dom * np.array([0.2, 0.5, 0.2], np.float32) + 3.3
+    c.src[1, 0, :] = dom * np.array([0.7, 0.4, 0.25], np.float32) + 1.7
+    return c
+
+
+def _run(mifwi, case, monkeypatch, box, budget_mb=None, dt=None, model_first=None):
+    monkeypatch.setenv("MIFWI_3D_BOX", "1" if box else "0")
+    if budget_mb is None:
+        monkeypatch.delenv("MIFWI_SAVE_BUDGET_MB", raising=False)
+    else:
+        monkeypatch.setenv("MIFWI_SAVE_BUDGET_MB", str(budget_mb))
+    p = case.prob
+    plan = mifwi.Plan(p.shape_pad, p.spacing, p.origin_pad, p.space_order, case.nt, dt or case.dt, 1, case.nrec,
+                      max_shots=case.nshots)
+    plan.set_geometry(case.src, case.rec)
+    if model_first is not None:   # an evaluation with another model first: whatever it leaves behind must not show
+        plan.set_model(model_first.vp, model_first.damp)
+        r0 = plan.forward(case.wavelet, save=True)
+        plan.gradient(r0)
+    plan.set_model(p.vp, p.damp)
+    rec_plain = np.array(plan.forward(case.wavelet))
+    last = np.array(plan.read_wavefield(1, shot=1))
+    rec = np.array(plan.forward(case.wavelet, save=True))
+    st = plan.stats()
+    saved = None if st["ckpt_steps"] else np.array(plan.read_wavefield(0, shot=0))
+    grad, illum = plan.gradient(rec, want_illum=True)
+    out = dict(rec_plain=rec_plain, last=last, rec=rec, saved=saved, grad=np.array(grad), illum=np.array(illum),
+               ckpt_steps=st["ckpt_steps"])
+    plan.close()
+    return out
+
+
+def _mb_of_levels(case, n):
+    """Device memory of n saved levels of both shots, in MiB (halo of the space order included)."""
+    field = np.prod(np.array(case.prob.shape_pad) + case.prob.space_order)
+    return int(n * case.nshots * field * 4 / 2 ** 20) + 1
+
+
+def _same(a, b, what):
+    for k in ("rec_plain", "last", "rec", "saved", "grad", "illum"):
+        if a[k] is None or b[k] is None:
+            assert a[k] is None and b[k] is None, (what, k)
+            continue
+        assert np.array_equal(a[k], b[k]), (what, k, float(np.abs(a[k] - b[k]).max()))
+
+
+def test_skipped_planes_equal_the_full_sweep(mifwi, monkeypatch):
+    case = _long_case()
+    full = _run(mifwi, case, monkeypatch, box=False)
+    skip = _run(mifwi, case, monkeypatch, box=True)
+    assert np.abs(full["rec"]).max() > 0 and np.abs(full["grad"]).max() > 0
+    # the premise: after these steps the ends of the grid are still exactly zero (shot 1 sits at 70 % of the length)
+    level = full["last"][(case.nt - 1) % 3]
+    assert not level[:20].any() and level[90:130].any()
+    _same(full, skip, "stored levels")
+
+
+def test_skipped_planes_with_checkpointed_levels(mifwi, monkeypatch):
+    case = _long_case()
+    full = _run(mifwi, case, monkeypatch, box=False)
+    skip = _run(mifwi, case, monkeypatch, box=True, budget_mb=_mb_of_levels(case, 32))
+    assert skip["ckpt_steps"] > 0
+    for k in ("rec_plain", "rec", "grad", "illum"):
+        assert np.array_equal(full[k], skip[k]), k
+
+
+def test_a_wider_wavefield_of_an_earlier_evaluation_leaves_nothing_behind(mifwi, monkeypatch):
+    case = _long_case()
+    fast = _long_case(scale=1.6)
+    dt = min(case.dt, fast.dt)
+    full = _run(mifwi, case, monkeypatch, box=False, dt=dt)
+    skip = _run(mifwi, case, monkeypatch, box=True, dt=dt, model_first=fast.prob)
+    _same(full, skip, "after a faster model")
+    ck = _run(mifwi, case, monkeypatch, box=True, dt=dt, model_first=fast.prob,
+              budget_mb=_mb_of_levels(case, 32))
+    assert ck["ckpt_steps"] > 0
+    for k in ("rec_plain", "rec", "grad", "illum"):
+        assert np.array_equal(full[k], ck[k]), k

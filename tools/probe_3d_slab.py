@@ -4,6 +4,7 @@ import os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "devito-fwi_amd")]
+os.environ.setdefault("MIFWI_3D_BOX", "0")   # steady-state step: every plane computed
 import mifwi
 from seismic import Model
 n, so, nt = 512, (int(sys.argv[1]) if len(sys.argv) > 1 else 16), 22
