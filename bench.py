@@ -200,8 +200,8 @@ def roofline_3d(mifwi, device, space_order=16, n=512, nbl=40, nt=14):
     g = np.linspace(0, (n - 1) * 10.0, 64, dtype=np.float32)
     rec = np.stack(np.meshgrid(g, g, indexing="ij"), -1).reshape(-1, 2)
     rec = np.concatenate([rec, np.full((rec.shape[0], 1), 20.0, np.float32)], 1)
-    # every plane computed: a forward loop otherwise only writes the planes the wave has not reached, which after
-    # these few steps is most of the grid
+    # every point computed: a forward loop otherwise skips what the wave has not reached, which after these few steps
+    # is most of the grid
     with _env("MIFWI_3D_BOX", "0"):
         plan = mifwi.Plan(sp, model.spacing, model.grid.origin, space_order, nt, dt, 1, rec.shape[0], max_shots=1,
                           device=device)
@@ -299,8 +299,8 @@ def c4_leg(mifwi, device, space_order=8, n=512, nbl=40, nt=500):
     out, grad_f32 = None, None
     # the float32 default first; then the same evaluation with the saved levels in half precision
     # (MIFWI_FLAG_SAVE_F16: every level fits, nothing is propagated twice; the gradient differs in the 5th digit)
-    # and in between the float32 evaluation with every plane of every forward step computed (MIFWI_3D_BOX=0): by
-    # default forward loops only write the x planes the wave has not reached yet, which are exactly zero
+    # and in between the float32 evaluation with every point of every step computed (MIFWI_3D_BOX=0): by default the
+    # loops compute nothing where the wave has not arrived yet, which is exactly zero
     for flags, box in ((0, "1"), (0, "0"), (mifwi.FLAG_SAVE_F16, "1")):
         with _env("MIFWI_3D_BOX", box):
             plan = mifwi.Plan(sp, model.spacing, model.grid.origin, space_order, nt, dt, 1, rec.shape[0], max_shots=1,
@@ -327,14 +327,14 @@ def c4_leg(mifwi, device, space_order=8, n=512, nbl=40, nt=500):
         if flags == 0 and box == "1":
             out = dict({"workload": "synthetic 3-D %d^3 (+nbl %d = %d^3), space_order=%d, nt=%d, 1 shot: forward + L2 "
                                     "gradient; the first %d steps checkpointed in segments of %d and propagated twice, "
-                                    "the levels of the other %d stored; forward steps write the x planes the wave has "
-                                    "not reached (exact zeros) without computing them" %
+                                    "the levels of the other %d stored; time loops compute nothing where the wave "
+                                    "has not arrived (exact zeros)" %
                                     (n, nbl, sp[0], space_order, nt, st["ckpt_steps"], st["ckpt_segment"],
                                      nt - 2 - st["ckpt_steps"])}, **leg)
             grad_f32 = grad
         elif flags == 0:
             leg["gradient_equal_to_default"] = bool(torch.equal(grad, grad_f32))
-            leg["what"] = "same evaluation with every plane of every forward step computed (MIFWI_3D_BOX=0)"
+            leg["what"] = "same evaluation with every point of every step computed (MIFWI_3D_BOX=0)"
             out["every_plane_computed"] = leg
         else:
             num = float(torch.linalg.vector_norm((grad - grad_f32).double()))

@@ -306,28 +306,37 @@ __global__ __launch_bounds__(TY *TZ / V, (XMODE == 1 || XMODE == 2 || XMODE >= 4
         h_glb[i] = h_ok[i] ? (unsigned)((a.off0 + (long)gy * a.s1 + (z0 - RZ + 4 * c4)) * 4) : kDead;
     }
 
-    // Forward loops keep, per shot, the range of planes in which any of their steps so far has produced a value other
-    // than zero (a.box_lo / a.box_hi, updated below).  R planes further out the two levels this step reads are still
-    // exactly zero and so is its result, unless something is injected there: those planes are written, not computed,
-    // and the planes that can hold something are shared out anew among the chunks.  (A range read while other blocks
+    // Time loops (forward, and backward without illumination sums: where the backward field and its two neighbours in
+    // time are zero a step's gradient term is zero, the squares of the forward field are not) keep, per shot, the box
+    // of grid points (a range per axis) in which any of their steps so far has
+    // produced a value other than zero (a.box_lo / a.box_hi: x, y, z ranges a.box_stride apart, updated below).  R
+    // points further out the two levels this step reads are still exactly zero and so is its result, unless something
+    // is injected there: those planes, and all planes of a tile the box does not reach, are written, not computed,
+    // and the planes that can hold something are shared out anew among the chunks.  (A box read while other blocks
     // of the launch widen it is a wider one: still correct.)
-    constexpr bool BOX = (XMODE == 0 || XMODE == 3);
+    constexpr bool BOX = (XMODE == 0 || XMODE == 1 || XMODE == 3 || XMODE == 4);
     int xa = oa, xb = ob;
     if (BOX && a.box_lo) {
-        int lo = min(a.box_lo[shot] - R, a.inj_xlo), hi = max(a.box_hi[shot] + R, a.inj_xhi);
+        const int bs = a.box_stride;
+        int lo = min(a.box_lo[shot] - R, a.inj_lo[0]), hi = max(a.box_hi[shot] + R, a.inj_hi[0]);
         lo = max(lo, a.x_lo), hi = min(hi, a.x_hi);
-        if (hi < lo) hi = lo;
+        const int ylo = min(a.box_lo[bs + shot] - R, a.inj_lo[1]), yhi = max(a.box_hi[bs + shot] + R, a.inj_hi[1]);
+        const int zlo = min(a.box_lo[2 * bs + shot] - R, a.inj_lo[2]), zhi = max(a.box_hi[2 * bs + shot] + R, a.inj_hi[2]);
+        const bool tile_on = ylo < y0 + TY && yhi > y0 && zlo < z0 + TZ && zhi > z0;
+        if (hi < lo || !tile_on) hi = lo;
         const int xc = (hi - lo + a.nchunk - 1) / a.nchunk;
         xa = min(hi, lo + chunk * xc), xb = min(hi, xa + xc);
         const float zero[V] = {};
         const bool ragged0 = !full && nlive > 0;
-        for (int x = oa; x < ob; ++x) {
+        for (int x = oa; (a.box_fill || MODE == 3) && x < ob; ++x) {
             if (x >= lo && x < hi) {
                 x = hi - 1;
                 continue;
             }
-            bstv_stream<V>(outB, (unsigned)x * sbu, col_s, zero);
-            if (__builtin_expect(ragged0, 0)) bstv_ragged<V>(outB, (unsigned)x * sbu, col, zero, nlive);
+            if (a.box_fill) {   // (not into a level that was cleared when the loop began and has stayed zero here)
+                bstv_stream<V>(outB, (unsigned)x * sbu, col_s, zero);
+                if (__builtin_expect(ragged0, 0)) bstv_ragged<V>(outB, (unsigned)x * sbu, col, zero, nlive);
+            }
             if (MODE == 3 && live) {
                 char *cb = reinterpret_cast<char *>(a.copy16) + (((long)shot * a.copy_shot_stride * 4 + (long)x * sb) >> 1);
                 if (full) {
@@ -665,9 +674,20 @@ __global__ __launch_bounds__(TY *TZ / V, (XMODE == 1 || XMODE == 2 || XMODE >= 4
             nz_lo = min(nz_lo, __shfl_xor(nz_lo, o));
             nz_hi = max(nz_hi, __shfl_xor(nz_hi, o));
         }
+        // a thread that has seen a value owns row y and points z .. z + nlive - 1
+        const bool any = nz_lo < nz_hi;
+        int ny_lo = any ? y : 0x7fffffff, ny_hi = any ? y + 1 : -0x7fffffff;
+        int nq_lo = any ? z : 0x7fffffff, nq_hi = any ? z + nlive : -0x7fffffff;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            ny_lo = min(ny_lo, __shfl_xor(ny_lo, o)), ny_hi = max(ny_hi, __shfl_xor(ny_hi, o));
+            nq_lo = min(nq_lo, __shfl_xor(nq_lo, o)), nq_hi = max(nq_hi, __shfl_xor(nq_hi, o));
+        }
         if ((tid & 63) == 0 && nz_lo < nz_hi) {
-            atomicMin(&a.box_lo[shot], nz_lo);
-            atomicMax(&a.box_hi[shot], nz_hi);
+            const int bs = a.box_stride;
+            atomicMin(&a.box_lo[shot], nz_lo), atomicMax(&a.box_hi[shot], nz_hi);
+            atomicMin(&a.box_lo[bs + shot], ny_lo), atomicMax(&a.box_hi[bs + shot], ny_hi);
+            atomicMin(&a.box_lo[2 * bs + shot], nq_lo), atomicMax(&a.box_hi[2 * bs + shot], nq_hi);
         }
     }
 }

@@ -155,6 +155,7 @@ static void destroy(Plan *p)
     dev_free(p->ckpt);
     dev_free(p->d_box);
     dev_free(p->d_ck_box);
+    dev_free(p->d_boxv);
     dev_free(p->seg);
     free_sparse(p->src);
     free_sparse(p->rec);
@@ -303,7 +304,7 @@ static int build_sparse(Plan &p, SparseSet &S, const T *coords /* [tables][npoin
     };
     std::vector<Entry> ent;
     S.max_count = 0;
-    S.x_lo = 0x7fffffff, S.x_hi = -0x7fffffff;
+    for (int d = 0; d < 3; ++d) S.c_lo[d] = 0x7fffffff, S.c_hi[d] = -0x7fffffff;
     for (int t = 0; t < tables; ++t) {
         ent.clear();
         for (int q = 0; q < npoint; ++q) {
@@ -368,7 +369,8 @@ static int build_sparse(Plan &p, SparseSet &S, const T *coords /* [tables][npoin
                 const long r1 = rel - (long)i0 * L.s0;
                 const int i1 = (int)(r1 / L.s1), i2 = (int)(r1 % L.s1);
                 cs[u] = C3{(i1 / p.tile_tx) * p.ntz + (i2 / p.tile_tz), i0, (i1 % p.tile_tx) * p.tile_tz + (i2 % p.tile_tz), u};
-                S.x_lo = std::min(S.x_lo, i0), S.x_hi = std::max(S.x_hi, i0 + 1);
+                const int ii[3] = {i0, i1, i2};
+                for (int d = 0; d < 3; ++d) S.c_lo[d] = std::min(S.c_lo[d], ii[d]), S.c_hi[d] = std::max(S.c_hi[d], ii[d] + 1);
             }
             std::sort(cs.begin(), cs.end(), [](const C3 &a, const C3 &b) {
                 if (a.tile != b.tile) return a.tile < b.tile;
@@ -1050,8 +1052,13 @@ static int forward_step(Plan &p, const LoopCtx<T> &c, const T *cur, const T *old
         if (inject) set_inject3(a, p.src, p);
         if (interp) set_interp3(a, p.rec, p.d_rec);
         if (p.box_active && inject && !born && x_lo < 0) {
-            a.box_lo = p.d_box, a.box_hi = p.d_box + p.cfg.max_shots;
-            a.inj_xlo = a.cell_ptr ? p.src.x_lo : 0x7fffffff, a.inj_xhi = a.cell_ptr ? p.src.x_hi : -0x7fffffff;
+            a.box_lo = p.d_box, a.box_hi = p.d_box + 3 * p.cfg.max_shots, a.box_stride = p.cfg.max_shots;
+            // the rotating levels are cleared when a forward loop begins and the box only grows: what lies outside it
+            // there is still zero; the saved array and the segment buffers hold what earlier loops left
+            const char *ob = (const char *)out, *rb = (const char *)p.rot_u;
+            a.box_fill = !(rb && ob >= rb && ob < rb + 3 * (size_t)p.cfg.max_shots * p.L.field * sizeof(T));
+            for (int d = 0; d < 3; ++d)
+                a.inj_lo[d] = a.cell_ptr ? p.src.c_lo[d] : 0x7fffffff, a.inj_hi[d] = a.cell_ptr ? p.src.c_hi[d] : -0x7fffffff;
         }
         a.cur = (const float *)cur, a.old = (const float *)old, a.out = (float *)out, a.time = time;
         if ((rc = ot4_prestep(p, c.a3, a, launches))) return rc;
@@ -1141,6 +1148,11 @@ static int backward_step(Plan &p, const LoopCtx<T> &c, const T *cur, const T *ol
         a.shot_stride = shot_stride;
         set_inject3(a, p.rec, p);
         if (!with_grad && pair_role != 1) set_interp3(a, p.src, p.d_srca);
+        if (p.box_active_v) {   // `out` is one of the rotating levels, cleared when the loop began
+            a.box_lo = p.d_boxv, a.box_hi = p.d_boxv + 3 * p.cfg.max_shots, a.box_stride = p.cfg.max_shots, a.box_fill = 0;
+            for (int d = 0; d < 3; ++d)
+                a.inj_lo[d] = a.cell_ptr ? p.rec.c_lo[d] : 0x7fffffff, a.inj_hi[d] = a.cell_ptr ? p.rec.c_hi[d] : -0x7fffffff;
+        }
         a.pair = (pair_role == 2);
         a.cur = (const float *)cur, a.old = (const float *)old, a.out = (float *)out, a.time = time;
         if ((rc = ot4_prestep(p, c.a3, a, launches))) return rc;
@@ -1489,15 +1501,15 @@ static int run_forward(Plan &p, int nshots, int save)
     };
     // planes the wave has not reached are written, not computed (2.5-D kernel, one step per launch)
     const bool box = p.kind == 2 && p.box_enabled && slab_w == 0;
-    if (box && !p.d_box && (rc = dev_alloc(p, (void **)&p.d_box, 2 * (size_t)p.cfg.max_shots * sizeof(int), true))) return rc;
+    if (box && !p.d_box && (rc = dev_alloc(p, (void **)&p.d_box, 6 * (size_t)p.cfg.max_shots * sizeof(int), true))) return rc;
     if (box && ckpt && !p.d_ck_box &&
-        (rc = dev_alloc(p, (void **)&p.d_ck_box, 2 * (size_t)p.cfg.max_shots * p.ck_nseg * sizeof(int), true)))
+        (rc = dev_alloc(p, (void **)&p.d_ck_box, 6 * (size_t)p.cfg.max_shots * p.ck_nseg * sizeof(int), true)))
         return rc;
     auto enqueue = [&](int &launches) -> int {
         if (slab_w > 0) return enqueue_slabs(launches);
         if (box) {   // empty range: lo = 0x7f7f7f7f, hi = 0x80808080 (negative)
-            MIFWI_HIP(hipMemsetAsync(p.d_box, 0x7f, (size_t)p.cfg.max_shots * sizeof(int), p.stream));
-            MIFWI_HIP(hipMemsetAsync(p.d_box + p.cfg.max_shots, 0x80, (size_t)p.cfg.max_shots * sizeof(int), p.stream));
+            MIFWI_HIP(hipMemsetAsync(p.d_box, 0x7f, 3 * (size_t)p.cfg.max_shots * sizeof(int), p.stream));
+            MIFWI_HIP(hipMemsetAsync(p.d_box + 3 * p.cfg.max_shots, 0x80, 3 * (size_t)p.cfg.max_shots * sizeof(int), p.stream));
         }
         for (int time = 1; time <= nt - 2; ++time) {
             if (ckpt && time <= p.ck_nc && (time - 1) % p.ck_K == 0) {
@@ -1509,8 +1521,8 @@ static int run_forward(Plan &p, int nshots, int save)
                 if ((r = copy_levels<T>(p, dst, cstride, lvl(time - 1), shot_stride, 1, nshots))) return r;
                 if ((r = copy_levels<T>(p, dst + L.field, cstride, lvl(time), shot_stride, 1, nshots))) return r;
                 if (box)   // and the range the two levels lie in
-                    MIFWI_HIP(hipMemcpyAsync(p.d_ck_box + (size_t)j * 2 * p.cfg.max_shots, p.d_box,
-                                             2 * (size_t)p.cfg.max_shots * sizeof(int), hipMemcpyDeviceToDevice, p.stream));
+                    MIFWI_HIP(hipMemcpyAsync(p.d_ck_box + (size_t)j * 6 * p.cfg.max_shots, p.d_box,
+                                             6 * (size_t)p.cfg.max_shots * sizeof(int), hipMemcpyDeviceToDevice, p.stream));
             }
             if (mixed && time > p.ck_nc) {
                 int r;
@@ -1620,8 +1632,20 @@ static int run_backward(Plan &p, int nshots, bool with_grad, bool with_illum)
         if (time % 2 == 0) return (time != nt - 2 && time >= 2) ? 1 : 0;
         return (time + 1 < nt - 2) ? 2 : 0;
     };
+    // where the backward field has not arrived nothing is computed (2.5-D kernel); the illumination sums need every point
+    const bool boxv = p.kind == 2 && p.box_enabled && !(with_grad && with_illum);
+    if (boxv && !p.d_boxv && (rc = dev_alloc(p, (void **)&p.d_boxv, 6 * (size_t)p.cfg.max_shots * sizeof(int), true))) return rc;
+    struct BoxScopeV {
+        Plan &p;
+        BoxScopeV(Plan &q, bool on) : p(q) { p.box_active_v = on; }
+        ~BoxScopeV() { p.box_active_v = false; }
+    } box_scope_v(p, boxv);
     auto enqueue = [&](int &launches) -> int {
         int r;
+        if (boxv) {   // empty box
+            MIFWI_HIP(hipMemsetAsync(p.d_boxv, 0x7f, 3 * (size_t)p.cfg.max_shots * sizeof(int), p.stream));
+            MIFWI_HIP(hipMemsetAsync(p.d_boxv + 3 * p.cfg.max_shots, 0x80, 3 * (size_t)p.cfg.max_shots * sizeof(int), p.stream));
+        }
         if (!ckpt) {
             // saved levels: float, or half precision (then the kernels take the pointers as raw addresses)
             const char *sv = (const char *)p.saved;
@@ -1663,8 +1687,8 @@ static int run_backward(Plan &p, int nshots, bool with_grad, bool with_illum)
                 return r;
             const bool box = p.kind == 2 && p.box_enabled && p.d_box && p.d_ck_box;
             if (box)   // the range the checkpointed levels lie in
-                MIFWI_HIP(hipMemcpyAsync(p.d_box, p.d_ck_box + (size_t)j * 2 * p.cfg.max_shots,
-                                         2 * (size_t)p.cfg.max_shots * sizeof(int), hipMemcpyDeviceToDevice, p.stream));
+                MIFWI_HIP(hipMemcpyAsync(p.d_box, p.d_ck_box + (size_t)j * 6 * p.cfg.max_shots,
+                                         6 * (size_t)p.cfg.max_shots * sizeof(int), hipMemcpyDeviceToDevice, p.stream));
             p.box_active = box;
             for (int time = t0; time <= t1; ++time) {
                 T *c = seg + (long)(time - t0 + 1) * L.field;

@@ -90,7 +90,7 @@ struct SparseSet {
     int32_t *cell_ptr = nullptr;   // [tables][ntiles][n0+1] ranges into cell_local / cell_uc
     int32_t *cell_local = nullptr; // [tables][kmax] tile-local (y,z) index of the cell
     int32_t *cell_uc = nullptr;    // [tables][kmax] index of the cell in uc_ptr
-    int x_lo = 0x7fffffff, x_hi = -0x7fffffff;   // planes lo <= x < hi that hold a cell of any table (host copy)
+    int c_lo[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff}, c_hi[3] = {-0x7fffffff, -0x7fffffff, -0x7fffffff};   // box of the cells of all tables, 2.5-D kernel (host copy)
 };
 
 struct Plan {
@@ -178,10 +178,10 @@ struct Plan {
     int xchunk = 0, nchunk = 0;
     int ncu = 256, bpc_fwd = 2, bpc_grad = 2;  // CUs and resident 2.5-D blocks per CU (plain / gradient)
     int nchunk_env = 0, nchunk_grad_env = 0;
-    // 2.5-D forward loops: per shot the range of planes that hold anything so far (lo[max_shots], hi[max_shots]), the
+    // 2.5-D forward loops: per shot the box that holds anything so far (lo[3][max_shots], hi[3][max_shots]), the
     // copies taken with the checkpoints, whether plans use it at all and whether the loop being enqueued does
-    int *d_box = nullptr, *d_ck_box = nullptr;
-    bool box_enabled = false, box_active = false;
+    int *d_box = nullptr, *d_ck_box = nullptr, *d_boxv = nullptr;   // (d_boxv: the backward field's)
+    bool box_enabled = false, box_active = false, box_active_v = false;
     int slab_w = 0, slab_chunks = 1;   // two-step sweeps of the 2.5-D kernel: planes per slab (0 = off), chunks per slab
     unsigned char *eta_zero = nullptr;  // 2.5-D kernel: [tile][n0] flags of sponge-free patches (scratch of the next)
     int *eta_free = nullptr;            // 2.5-D kernel: [tile][2] longest run lo <= x < hi of sponge-free planes
@@ -567,10 +567,13 @@ struct Step3DArgs {
     float pre_c;
     const float *bih;
     long cur_shot_stride, out_shot_stride;
-    // forward loops (null otherwise): per shot the range of planes lo <= x < hi in which the loop's steps so far have
-    // produced a value other than zero, read and widened by the kernel; planes inj_xlo <= x < inj_xhi hold injected cells
+    // forward loops and backward loops without illumination sums (null otherwise): per shot the box lo <= i < hi (x, then y, then z, box_stride ints apart) in which
+    // the loop's steps so far have produced a value other than zero, read and widened by the kernel; inj_lo / inj_hi:
+    // the box of the injected cells
     int *box_lo, *box_hi;
-    int inj_xlo, inj_xhi;
+    int box_stride;
+    int box_fill;   // store zeros where nothing is computed (0: `out` was cleared when the loop began)
+    int inj_lo[3], inj_hi[3];
 };
 int launch_step3d(const Plan &p, const Step3DArgs &a, hipStream_t stream);
 int launch_eta_zero(const Plan &p, unsigned char *flags, int *free_range);

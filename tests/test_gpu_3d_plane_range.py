@@ -1,6 +1,7 @@
-"""Forward loops of the 2.5-D kernel write, without computing them, the x planes the wave has not reached yet (the
-library keeps the range of planes that hold a value other than zero and widens it by the stencil radius per step).
-The result must be the one of the full sweep, value for value: `MIFWI_3D_BOX=0` switches the skipping off.
+"""Time loops of the 2.5-D kernel compute nothing where the wave has not arrived yet: the library keeps, per shot, the
+box of points that hold a value other than zero, widens it by the stencil radius per step and leaves out the x planes
+and the (y, z) tiles outside it (forward loops, recomputed segments, adjoint loops, gradient loops without illumination
+sums).  The result must be the one of the full sweep, value for value: `MIFWI_3D_BOX=0` switches the skipping off.
 The reference has no counterpart (Devito sweeps the whole grid every step); parity of the 3-D kernels with the CPU
 restatement is tested in test_gpu_parity_abi.py and test_gpu_golden.py with the skipping on."""
 import numpy as np
@@ -28,6 +29,17 @@ def _long_case(scale=1.0, nt=44, seed=5):
     return c
 
 
+def _wide_case(nt=22, seed=9):
+    """A grid of several tiles in y (16 rows each) and z (64 points each) with both sources in one corner region: most
+    tiles stay out of the wave's reach for these steps."""
+    shape = (40, 150, 246)
+    c = Case(shape, (10.0, 10.0, 10.0), nbl=5, space_order=4, nt=nt, nshots=2, nrec=13, seed=seed)
+    dom = np.array([(n - 1) * 10.0 for n in shape], dtype=np.float32)
+    c.src[0, 0, :] = dom * np.array([0.5, 0.08, 0.05], np.float32) + 2.1
+    c.src[1, 0, :] = dom * np.array([0.4, 0.12, 0.08], np.float32) + 4.4
+    return c
+
+
 def _run(mifwi, case, monkeypatch, box, budget_mb=None, dt=None, model_first=None):
     monkeypatch.setenv("MIFWI_3D_BOX", "1" if box else "0")
     if budget_mb is None:
@@ -49,7 +61,11 @@ def _run(mifwi, case, monkeypatch, box, budget_mb=None, dt=None, model_first=Non
     st = plan.stats()
     saved = None if st["ckpt_steps"] else np.array(plan.read_wavefield(0, shot=0))
     grad, illum = plan.gradient(rec, want_illum=True)
-    out = dict(rec_plain=rec_plain, last=last, rec=rec, saved=saved, grad=np.array(grad), illum=np.array(illum),
+    grad, illum = np.array(grad), np.array(illum)
+    # without the illumination sums the backward loop skips what its field has not reached as well
+    grad_only = np.array(plan.gradient(rec))
+    srca = np.array(plan.adjoint(rec))
+    out = dict(rec_plain=rec_plain, last=last, rec=rec, saved=saved, grad=grad, illum=illum, grad_only=grad_only, srca=srca,
                ckpt_steps=st["ckpt_steps"])
     plan.close()
     return out
@@ -62,7 +78,7 @@ def _mb_of_levels(case, n):
 
 
 def _same(a, b, what):
-    for k in ("rec_plain", "last", "rec", "saved", "grad", "illum"):
+    for k in ("rec_plain", "last", "rec", "saved", "grad", "illum", "grad_only", "srca"):
         if a[k] is None or b[k] is None:
             assert a[k] is None and b[k] is None, (what, k)
             continue
@@ -78,6 +94,20 @@ def test_skipped_planes_equal_the_full_sweep(mifwi, monkeypatch):
     level = full["last"][(case.nt - 1) % 3]
     assert not level[:20].any() and level[90:130].any()
     _same(full, skip, "stored levels")
+    assert np.array_equal(skip["grad"], skip["grad_only"])
+
+
+def test_skipped_tiles_equal_the_full_sweep(mifwi, monkeypatch):
+    case = _wide_case()
+    full = _run(mifwi, case, monkeypatch, box=False)
+    skip = _run(mifwi, case, monkeypatch, box=True)
+    level = full["last"][(case.nt - 1) % 3]
+    assert not level[:, 128:, :].any() and not level[:, :, 192:].any() and level[:, :48, :64].any()
+    _same(full, skip, "tiles out of reach")
+    ck = _run(mifwi, case, monkeypatch, box=True, budget_mb=_mb_of_levels(case, 20))
+    assert ck["ckpt_steps"] > 0
+    for k in ("rec_plain", "rec", "grad", "illum", "grad_only", "srca"):
+        assert np.array_equal(full[k], ck[k]), k
 
 
 def test_skipped_planes_with_checkpointed_levels(mifwi, monkeypatch):
@@ -85,7 +115,7 @@ def test_skipped_planes_with_checkpointed_levels(mifwi, monkeypatch):
     full = _run(mifwi, case, monkeypatch, box=False)
     skip = _run(mifwi, case, monkeypatch, box=True, budget_mb=_mb_of_levels(case, 32))
     assert skip["ckpt_steps"] > 0
-    for k in ("rec_plain", "rec", "grad", "illum"):
+    for k in ("rec_plain", "rec", "grad", "illum", "grad_only", "srca"):
         assert np.array_equal(full[k], skip[k]), k
 
 
@@ -99,5 +129,5 @@ def test_a_wider_wavefield_of_an_earlier_evaluation_leaves_nothing_behind(mifwi,
     ck = _run(mifwi, case, monkeypatch, box=True, dt=dt, model_first=fast.prob,
               budget_mb=_mb_of_levels(case, 32))
     assert ck["ckpt_steps"] > 0
-    for k in ("rec_plain", "rec", "grad", "illum"):
+    for k in ("rec_plain", "rec", "grad", "illum", "grad_only", "srca"):
         assert np.array_equal(full[k], ck[k]), k
