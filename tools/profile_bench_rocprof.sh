@@ -5,6 +5,9 @@
 tag=${1:-r3}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/$tag
+# the 3-D kernels are profiled sweeping the whole grid (by default their loops skip what the wave has not reached,
+# and a mean over such launches describes no launch)
+export MIFWI_3D_BOX=0
 CMD="python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-batches --no-strong"
 timeout -k 10 400 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/$tag/trace -o bench -- $CMD > gpurun_out/$tag/trace.log 2>&1 || { echo trace failed; tail -5 gpurun_out/$tag/trace.log; exit 1; }
 timeout -s KILL 300 rocprofv3 --pmc FETCH_SIZE -d gpurun_out/$tag/p1 -o pmc --output-format csv -- $CMD > gpurun_out/$tag/p1.log 2>&1 || { echo pmc1 failed; tail -5 gpurun_out/$tag/p1.log; exit 1; }

@@ -65,7 +65,7 @@ def entry(parts):
 
 # grids of the benchmark: 8 shots x 98 tiles of 32 x 32 (+ 16 interpolation blocks in forward loops), 256 threads;
 # 592^3: 370 tiles x 6 chunks (+ 16 interpolation blocks) forward, 370 x 4 chunks in the gradient loop
-traffic = {"_comment": "Per launch, from rocprofv3 of `python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-batches --no-strong`: mean "
+traffic = {"_comment": "Per launch, from rocprofv3 of `MIFWI_3D_BOX=0 python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-batches --no-strong` (3-D loops sweeping the whole grid): mean "
                        "duration from the kernel trace, fabric-side bytes = 2 x FETCH_SIZE + WRITE_SIZE (FETCH_SIZE "
                        "tallies 128-byte requests at 64 bytes on gfx950). For the 2-D kernels the working set lives in "
                        "the 256 MB last-level cache: these are bytes leaving the L2s, an upper bound on HBM traffic. "
