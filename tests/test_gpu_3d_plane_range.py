@@ -40,15 +40,15 @@ def _wide_case(nt=22, seed=9):
     return c
 
 
-def _run(mifwi, case, monkeypatch, box, budget_mb=None, dt=None, model_first=None):
+def _run(mifwi, case, monkeypatch, box, budget_mb=None, dt=None, model_first=None, flags=0):
     monkeypatch.setenv("MIFWI_3D_BOX", "1" if box else "0")
     if budget_mb is None:
         monkeypatch.delenv("MIFWI_SAVE_BUDGET_MB", raising=False)
     else:
         monkeypatch.setenv("MIFWI_SAVE_BUDGET_MB", str(budget_mb))
     p = case.prob
-    plan = mifwi.Plan(p.shape_pad, p.spacing, p.origin_pad, p.space_order, case.nt, dt or case.dt, 1, case.nrec,
-                      max_shots=case.nshots)
+    plan = mifwi.Plan(p.shape_pad, p.spacing, p.origin_pad, p.space_order, case.nt, dt or case.dt, case.nsrc, case.nrec,
+                      max_shots=case.nshots, flags=flags)
     plan.set_geometry(case.src, case.rec)
     if model_first is not None:   # an evaluation with another model first: whatever it leaves behind must not show
         plan.set_model(model_first.vp, model_first.damp)
@@ -59,7 +59,7 @@ def _run(mifwi, case, monkeypatch, box, budget_mb=None, dt=None, model_first=Non
     last = np.array(plan.read_wavefield(1, shot=1))
     rec = np.array(plan.forward(case.wavelet, save=True))
     st = plan.stats()
-    saved = None if st["ckpt_steps"] else np.array(plan.read_wavefield(0, shot=0))
+    saved = None if (st["ckpt_steps"] or flags & mifwi.FLAG_SAVE_F16) else np.array(plan.read_wavefield(0, shot=0))
     grad, illum = plan.gradient(rec, want_illum=True)
     grad, illum = np.array(grad), np.array(illum)
     # without the illumination sums the backward loop skips what its field has not reached as well
@@ -131,3 +131,19 @@ def test_a_wider_wavefield_of_an_earlier_evaluation_leaves_nothing_behind(mifwi,
     assert ck["ckpt_steps"] > 0
     for k in ("rec_plain", "rec", "grad", "illum", "grad_only", "srca"):
         assert np.array_equal(full[k], ck[k]), k
+
+
+def test_half_precision_levels_and_several_sources_per_shot(mifwi, monkeypatch):
+    """The half-precision copy of a level gets its zeros too (an evaluation with a faster model first), and the box
+    of the injected cells spans all sources of a shot."""
+    case = _long_case()
+    fast = _long_case(scale=1.6)
+    dt = min(case.dt, fast.dt)
+    full = _run(mifwi, case, monkeypatch, box=False, dt=dt, flags=mifwi.FLAG_SAVE_F16)
+    skip = _run(mifwi, case, monkeypatch, box=True, dt=dt, model_first=fast.prob, flags=mifwi.FLAG_SAVE_F16)
+    _same(full, skip, "half-precision levels")
+    shape = (150, 22, 34)
+    multi = Case(shape, (10.0, 10.0, 10.0), nbl=5, space_order=8, nt=40, nshots=2, nrec=9, nsrc=3, seed=21)
+    dom = np.array([(n - 1) * 10.0 for n in shape], dtype=np.float32)
+    multi.src[..., 0] = (0.15 + 0.1 * np.arange(3, dtype=np.float32))[None, :] * dom[0] + np.array([[0.0], [600.0]], np.float32)
+    _same(_run(mifwi, multi, monkeypatch, box=False), _run(mifwi, multi, monkeypatch, box=True), "three sources per shot")
