@@ -199,6 +199,9 @@ __device__ inline void lds_stv(float *p, const float (&d)[V])
 // 139 at radius 8); the gradient variants, which carry five more vectors (163 at radius 8), are launched for 2
 // blocks per CU: a third measured no faster, they are bound by their bytes.
 // GRAD: also accumulate the FWI gradient.  ISO: equal spacing in x, y and z (one coefficient set).
+#ifndef MIFWI_3D_FWD_WAVES
+#define MIFWI_3D_FWD_WAVES 3
+#endif
 #ifndef MIFWI_3D_GRAD_WAVES
 #define MIFWI_3D_GRAD_WAVES 2
 #endif
@@ -208,7 +211,7 @@ __device__ inline void lds_stv(float *p, const float (&d)[V])
 // The fourth-order-in-time kernel (Step2DArgs::pt, pre_mode, bih) has variants of its own, so that the common ones
 // carry none of it: 5 = mode 0, 6 = mode 1, 7 = mode 2 with those arguments honoured.
 template <int R, int TY, int TZ, int V, int XMODE, bool ISO>
-__global__ __launch_bounds__(TY *TZ / V, (XMODE == 1 || XMODE == 2 || XMODE >= 4 ? MIFWI_3D_GRAD_WAVES : 3) * (V == 2 ? 2 : 1)) void step3d_kernel(Step3DArgs a)
+__global__ __launch_bounds__(TY *TZ / V, (XMODE == 1 || XMODE == 2 || XMODE >= 4 ? MIFWI_3D_GRAD_WAVES : MIFWI_3D_FWD_WAVES) * (V == 2 ? 2 : 1)) void step3d_kernel(Step3DArgs a)
 {
     constexpr bool OT4 = XMODE >= 5;
     constexpr int MODE = XMODE == 5 ? 0 : (XMODE == 6 ? 1 : (XMODE == 7 ? 2 : XMODE));
